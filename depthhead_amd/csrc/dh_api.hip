@@ -1,0 +1,652 @@
+// dh_api.hip -- host runtime behind the C ABI of include/depthhead_hip.h: forest validation,
+// HBM residency of the forest and its per-leaf tables, the per-batch workspace, kernel sequencing
+// on a caller-supplied HIP stream, profiling events and the parity taps.
+//
+// Sits where HoughPrediction::predict_parameter_generic sits in the reference
+// (src/hough/prediction.rs:421-493); the unit of work is a batch of frames.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dh_internal.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? DH_ENOMEM : DH_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *dh_last_error(void) { return g_err; }
+extern "C" int dh_version(void) { return DH_VERSION; }
+
+// ------------------------------------------------------------------ forest (host side)
+struct dh_forest {
+    std::vector<int32_t> roots;
+    std::vector<dh_node> nodes;
+    std::vector<double> leaf_prob;
+    std::vector<uint32_t> off_begin, rot_begin;
+    std::vector<float> offsets;
+    std::vector<double> rotations;
+    uint32_t max_depth = 0;
+    uint16_t max_x = 0, max_y = 0;   // largest rectangle corner used by any node
+};
+
+static inline int32_t rot_bin_host(double deg) {
+    // (deg * 120 / 360) as i32 + 60 (prediction.rs:605-613); only used to validate the forest
+    double v = deg * 120.0 / 360.0;
+    int32_t r;
+    if (v != v) r = 0;
+    else if (v >= 2147483648.0) r = INT32_MAX;
+    else if (v <= -2147483648.0) r = INT32_MIN;
+    else r = (int32_t)v;
+    return (int32_t)((uint32_t)r + 60u);
+}
+
+extern "C" int dh_forest_create(const dh_forest_desc *d, dh_forest **out) {
+    if (!d || !out) return fail(DH_EINVAL, "dh_forest_create: NULL argument");
+    *out = nullptr;
+    if (d->n_trees == 0 || !d->roots) return fail(DH_EINVAL, "forest has no trees");
+    if (d->n_leaves == 0 || !d->leaf_prob || !d->off_begin || !d->rot_begin) return fail(DH_EINVAL, "forest has no leaves");
+    if (d->n_nodes && !d->nodes) return fail(DH_EINVAL, "nodes is NULL");
+    if (d->n_nodes > 0x7fffffffu || d->n_leaves > 0x7fffffffu) return fail(DH_EINVAL, "forest too large");
+    const uint32_t NL = d->n_leaves, NN = d->n_nodes;
+    if (d->off_begin[0] != 0 || d->rot_begin[0] != 0) return fail(DH_EFOREST, "CSR arrays must start at 0");
+    for (uint32_t i = 0; i < NL; ++i)
+        if (d->off_begin[i + 1] < d->off_begin[i] || d->rot_begin[i + 1] < d->rot_begin[i])
+            return fail(DH_EFOREST, "CSR arrays not monotone at leaf %u", i);
+    const uint32_t n_off = d->off_begin[NL], n_rot = d->rot_begin[NL];
+    if ((n_off && !d->offsets) || (n_rot && !d->rotations)) return fail(DH_EINVAL, "vote arrays are NULL");
+
+    dh_forest *f = new (std::nothrow) dh_forest;
+    if (!f) return fail(DH_ENOMEM, "out of host memory");
+    try {
+        f->roots.assign(d->roots, d->roots + d->n_trees);
+        f->nodes.assign(d->nodes, d->nodes + NN);
+        f->leaf_prob.assign(d->leaf_prob, d->leaf_prob + NL);
+        f->off_begin.assign(d->off_begin, d->off_begin + NL + 1);
+        f->rot_begin.assign(d->rot_begin, d->rot_begin + NL + 1);
+        f->offsets.assign(d->offsets, d->offsets + (size_t)n_off * 3);
+        f->rotations.assign(d->rotations, d->rotations + (size_t)n_rot * 3);
+    } catch (...) {
+        delete f;
+        return fail(DH_ENOMEM, "out of host memory");
+    }
+
+    // ---- structure: every child in range, every node reached at most once (a forest of trees:
+    // guarantees each walk ends after at most max_depth steps), rectangles well-formed
+    std::vector<uint8_t> seen(NN, 0);
+    std::vector<std::pair<int32_t, uint32_t>> stack;
+    auto bad = [&](int code, const char *msg, long a) { delete f; return fail(code, msg, a); };
+    for (uint32_t t = 0; t < d->n_trees; ++t) {
+        int32_t r = f->roots[t];
+        if (r >= 0 ? (uint32_t)r >= NN : (uint32_t)(~r) >= NL) return bad(DH_EFOREST, "root of tree %ld out of range", t);
+        if (r < 0) continue;
+        stack.clear();
+        stack.push_back({r, 1u});
+        while (!stack.empty()) {
+            auto [n, depth] = stack.back();
+            stack.pop_back();
+            if (seen[n]) return bad(DH_EFOREST, "node %ld is reachable twice (cycle or shared subtree)", n);
+            seen[n] = 1;
+            f->max_depth = std::max(f->max_depth, depth);
+            const dh_node &nd = f->nodes[n];
+            for (const uint16_t *rc : {nd.r1, nd.r2}) {
+                if (rc[2] < rc[0] || rc[3] < rc[1]) return bad(DH_EFOREST, "node %ld: rectangle with negative extent", n);
+                f->max_x = std::max(f->max_x, rc[2]);
+                f->max_y = std::max(f->max_y, rc[3]);
+            }
+            if (nd.threshold != nd.threshold) return bad(DH_EFOREST, "node %ld: NaN threshold", n);
+            for (int32_t c : {nd.child_zero, nd.child_one}) {
+                if (c >= 0) {
+                    if ((uint32_t)c >= NN) return bad(DH_EFOREST, "node %ld: child out of range", n);
+                    stack.push_back({c, depth + 1});
+                } else if ((uint32_t)(~c) >= NL) {
+                    return bad(DH_EFOREST, "node %ld: leaf out of range", n);
+                }
+            }
+        }
+    }
+    // ---- leaves that can vote
+    for (uint32_t L = 0; L < NL; ++L) {
+        if (!(f->leaf_prob[L] > 0.0)) continue;
+        if (f->off_begin[L + 1] == f->off_begin[L]) return bad(DH_EFOREST, "leaf %ld: prob > 0 but no offsets (reference divides by zero)", L);
+        if (f->rot_begin[L + 1] == f->rot_begin[L]) return bad(DH_EFOREST, "leaf %ld: prob > 0 but no rotations (reference unwraps None)", L);
+        for (uint32_t i = f->rot_begin[L]; i < f->rot_begin[L + 1]; ++i)
+            for (int k = 0; k < 3; ++k) {
+                int32_t r = rot_bin_host(f->rotations[(size_t)i * 3 + k]);
+                if (r >= DH_ROT_GRID_PARTS) r -= DH_ROT_GRID_PARTS;
+                else if (r < 0) r += DH_ROT_GRID_PARTS;
+                if (r < 0 || r >= DH_ROT_GRID_PARTS) return bad(DH_EFOREST, "leaf %ld: rotation bin outside [0,120) after one wrap (reference indexes out of bounds)", L);
+            }
+    }
+    *out = f;
+    return DH_OK;
+}
+
+extern "C" int dh_forest_destroy(dh_forest *f) {
+    delete f;
+    return DH_OK;
+}
+
+extern "C" int dh_forest_info(const dh_forest *f, uint32_t *n_trees, uint32_t *n_nodes, uint32_t *n_leaves, uint32_t *max_depth) {
+    if (!f) return fail(DH_EINVAL, "dh_forest_info: NULL forest");
+    if (n_trees) *n_trees = (uint32_t)f->roots.size();
+    if (n_nodes) *n_nodes = (uint32_t)f->nodes.size();
+    if (n_leaves) *n_leaves = (uint32_t)f->leaf_prob.size();
+    if (max_depth) *max_depth = f->max_depth;
+    return DH_OK;
+}
+
+// ------------------------------------------------------------------ geometry
+struct Geom {
+    int w = 0, h = 0, nx = 0, ny = 0, npatch = 0;
+    int px = 0, py = 0, tiles_x = 0, tiles_y = 0, ss_max = 0;
+    size_t lds = 0;
+};
+
+static int patch_grid(const dh_params &p, int w, int h, int *nx, int *ny) {
+    if (p.stepwidth == 0 || p.subimage_width == 0 || p.subimage_height == 0) return fail(DH_EINVAL, "zero stepwidth / patch size");
+    if (w <= 0 || h <= 0) return fail(DH_EINVAL, "non-positive frame size");
+    // the reference computes `h - right_h` in u32 and panics in SubImage::new when the frame is
+    // smaller than the patch (prediction.rs:546-548, :565)
+    if ((uint32_t)w < p.subimage_width || (uint32_t)h < p.subimage_height) return fail(DH_ESIZE, "frame %dx%d smaller than the %ux%u patch", w, h, p.subimage_width, p.subimage_height);
+    uint32_t lw = p.subimage_width / 2, rw = p.subimage_width - lw, lh = p.subimage_height / 2, rh = p.subimage_height - lh;
+    uint32_t xe = (uint32_t)w - rw, ye = (uint32_t)h - rh;
+    *nx = xe > lw ? (int)((xe - lw + p.stepwidth - 1) / p.stepwidth) : 0;
+    *ny = ye > lh ? (int)((ye - lh + p.stepwidth - 1) / p.stepwidth) : 0;
+    return DH_OK;
+}
+
+extern "C" int dh_patch_grid(const dh_params *p, int w, int h, int *nx, int *ny) {
+    if (!p || !nx || !ny) return fail(DH_EINVAL, "dh_patch_grid: NULL argument");
+    return patch_grid(*p, w, h, nx, ny);
+}
+
+// ------------------------------------------------------------------ predictor
+struct dh_predictor {
+    int device = 0;
+    dh_params params{};
+    uint32_t n_trees = 0, n_nodes = 0, n_leaves = 0, n_off = 0, n_rot = 0, max_depth = 0;
+    DevForest dev{};
+    std::vector<void *> forest_allocs;
+    float *kern_ord = nullptr;   // device, 8000 floats
+    hipStream_t own_stream = nullptr;
+    // workspace
+    Geom geom;
+    int cap_frames = 0;
+    uint16_t *ws_frames = nullptr;   // host-API staging only
+    size_t ws_frames_bytes = 0;
+    HitRec *hits = nullptr;
+    uint32_t hits_cap = 0;
+    uint32_t *counters = nullptr;    // [n] hit_count | [n][400] pos_grid | [n][8000] rot_grid (one memset)
+    dh_pose *ws_poses = nullptr;
+    float *ws_midp = nullptr;
+    double *ws_rot = nullptr;
+    uint8_t *ws_mask = nullptr;
+    // taps
+    bool debug = false;
+    int32_t *dbg_leaf = nullptr;
+    uint8_t *dbg_flags = nullptr;
+    int32_t *dbg_guess = nullptr, *dbg_trace = nullptr;
+    uint32_t *dbg_steps = nullptr;
+    int32_t *dbg_votes = nullptr;
+    size_t dbg_votes_cap = 0;
+    uint32_t *dbg_vcount = nullptr;
+    bool dbg_valid = false;
+    // last batch
+    int last_n = 0;
+    const uint16_t *last_frames = nullptr;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+template <typename T>
+static int dev_alloc(dh_predictor *p, T **out, size_t count, bool track_forest = false) {
+    void *ptr = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&ptr, bytes);
+    if (e != hipSuccess) return fail(DH_ENOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    if (track_forest) p->forest_allocs.push_back(ptr);
+    *out = (T *)ptr;
+    return DH_OK;
+}
+template <typename T>
+static int upload(dh_predictor *p, const T **out, const std::vector<T> &v) {
+    T *d = nullptr;
+    int rc = dev_alloc(p, &d, v.size(), true);
+    if (rc) return rc;
+    if (!v.empty()) HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = d;
+    return DH_OK;
+}
+
+// Mat3<f32>::inv = adjugate / det, element-wise (meancov_estimation.rs:339-352); f32, no FMA
+// (this translation unit is compiled with -ffp-contract=off).
+static void mat3_inv_f32(const float m[9], float o[9]) {
+    const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const float det = a * (e * i - f * h) - d * (b * i - c * h) + g * (b * f - c * e);   // :340-342
+    o[0] = (e * i - f * h) / det; o[1] = (c * h - b * i) / det; o[2] = (b * f - c * e) / det;   // :348-350
+    o[3] = (f * g - d * i) / det; o[4] = (a * i - c * g) / det; o[5] = (c * d - a * f) / det;
+    o[6] = (d * h - e * g) / det; o[7] = (b * g - a * h) / det; o[8] = (a * e - b * d) / det;
+}
+
+// FullArray3D::build_kernel(20, sigma) (meanshift.rs:228-252), stored in summation order
+// (dx*20+dy)*20+dz; the reference indexes kernel[(x+10, y+10, z+10)] = data[z*400 + y*20 + x].
+static int build_kernel_table(dh_predictor *p) {
+    std::vector<float> k(DH_GRID3);
+    for (int x = 0; x < DH_GRID; ++x)
+        for (int y = 0; y < DH_GRID; ++y)
+            for (int z = 0; z < DH_GRID; ++z) {
+                int dx = x - 10, dy = y - 10, dz = z - 10;
+                int norm = dx * dx + dy * dy + dz * dz;
+                k[(x * DH_GRID + y) * DH_GRID + z] = expf(-1.0f * (float)norm / (2.0f * p->params.gaussian_sigma));
+            }
+    HIP_TRY(hipMemcpy(p->kern_ord, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
+    return DH_OK;
+}
+
+static void free_workspace(dh_predictor *p) {
+    void *ptrs[] = {p->ws_frames, p->hits, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
+                    p->dbg_flags, p->dbg_guess, p->dbg_trace, p->dbg_steps, p->dbg_votes, p->dbg_vcount};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    p->ws_frames = nullptr; p->hits = nullptr; p->counters = nullptr; p->ws_poses = nullptr; p->ws_midp = nullptr;
+    p->ws_rot = nullptr; p->ws_mask = nullptr; p->dbg_leaf = nullptr; p->dbg_flags = nullptr; p->dbg_guess = nullptr;
+    p->dbg_trace = nullptr; p->dbg_steps = nullptr; p->dbg_votes = nullptr; p->dbg_vcount = nullptr;
+    p->ws_frames_bytes = 0; p->dbg_votes_cap = 0; p->cap_frames = 0; p->hits_cap = 0; p->dbg_valid = false;
+    p->geom = Geom();
+}
+
+extern "C" int dh_predictor_destroy(dh_predictor *p) {
+    if (!p) return DH_OK;
+    (void)hipSetDevice(p->device);
+    if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
+    free_workspace(p);
+    for (void *q : p->forest_allocs) (void)hipFree(q);
+    if (p->kern_ord) (void)hipFree(p->kern_ord);
+    for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
+    if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+    delete p;
+    return DH_OK;
+}
+
+extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int device, dh_predictor **out) {
+    if (!f || !prm || !out) return fail(DH_EINVAL, "dh_predictor_create: NULL argument");
+    *out = nullptr;
+    if (prm->stepwidth == 0 || prm->subimage_width == 0 || prm->subimage_height == 0) return fail(DH_EINVAL, "zero stepwidth / patch size");
+    if (prm->subimage_width > 4096 || prm->subimage_height > 4096) return fail(DH_ESIZE, "patch larger than 4096");
+    // rect sums are taken modulo 2^32: exact while sw*sh*65535 < 2^32
+    if ((uint64_t)prm->subimage_width * prm->subimage_height * 65535ull >= (1ull << 32)) return fail(DH_ESIZE, "patch area %ux%u too large for u32 rectangle sums", prm->subimage_width, prm->subimage_height);
+    if (!(prm->gaussian_sigma == prm->gaussian_sigma)) return fail(DH_EINVAL, "sigma is NaN");
+    if (f->max_x > prm->subimage_width || f->max_y > prm->subimage_height)
+        return fail(DH_EFOREST, "a split rectangle (max corner %u,%u) leaves the %ux%u patch", f->max_x, f->max_y, prm->subimage_width, prm->subimage_height);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(DH_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    dh_predictor *p = new (std::nothrow) dh_predictor;
+    if (!p) return fail(DH_ENOMEM, "out of host memory");
+    p->device = device;
+    p->params = *prm;
+    p->n_trees = (uint32_t)f->roots.size(); p->n_nodes = (uint32_t)f->nodes.size(); p->n_leaves = (uint32_t)f->leaf_prob.size();
+    p->n_off = f->off_begin.back(); p->n_rot = f->rot_begin.back(); p->max_depth = f->max_depth;
+    int rc = DH_OK;
+    DevForest &d = p->dev;
+    d.n_trees = p->n_trees; d.n_nodes = p->n_nodes; d.n_leaves = p->n_leaves; d.n_off = p->n_off; d.n_rot = p->n_rot;
+#define STEP(x) if (rc == DH_OK) rc = (x)
+    STEP(upload(p, &d.roots, f->roots));
+    STEP(upload(p, &d.nodes, f->nodes));
+    STEP(upload(p, &d.leaf_prob, f->leaf_prob));
+    STEP(upload(p, &d.off_begin, f->off_begin));
+    STEP(upload(p, &d.rot_begin, f->rot_begin));
+    STEP(upload(p, &d.offsets, f->offsets));
+    STEP(upload(p, &d.rotations, f->rotations));
+    STEP(dev_alloc(p, &d.leaf_v, p->n_leaves, true));
+    STEP(dev_alloc(p, &d.leaf_flags, p->n_leaves, true));
+    STEP(dev_alloc(p, &d.rot_bin, p->n_rot, true));
+    STEP(dev_alloc(p, &d.rot_rough, p->n_rot, true));
+    STEP(dev_alloc(p, &d.off_min, (size_t)p->n_leaves * 3, true));
+    STEP(dev_alloc(p, &d.off_max, (size_t)p->n_leaves * 3, true));
+    STEP(dev_alloc(p, &d.rbin_box, p->n_leaves, true));
+    STEP(dev_alloc(p, &d.rbin_box_hi, p->n_leaves, true));
+    STEP(dev_alloc(p, &p->kern_ord, DH_GRID3));
+#undef STEP
+    auto hipstep = [&](hipError_t e, const char *what) {
+        if (rc == DH_OK && e != hipSuccess) rc = fail(DH_EHIP, "%s: %s", what, hipGetErrorString(e));
+    };
+    if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking), "hipStreamCreate");
+    if (rc == DH_OK) hipstep(dh_launch_leaf_prepare(d, p->own_stream), "k_leaf_prepare launch");
+    if (rc == DH_OK) hipstep(hipStreamSynchronize(p->own_stream), "k_leaf_prepare");
+    if (rc == DH_OK) rc = build_kernel_table(p);
+    for (auto &e : p->ev)
+        if (rc == DH_OK) hipstep(hipEventCreate(&e), "hipEventCreate");
+    if (rc != DH_OK) {
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);
+        dh_predictor_destroy(p);
+        memcpy(g_err, keep, sizeof keep);
+        return rc;
+    }
+    *out = p;
+    return DH_OK;
+}
+
+extern "C" int dh_predictor_update_sigma(dh_predictor *p, float val) {
+    if (!p) return fail(DH_EINVAL, "NULL predictor");
+    if (val == p->params.gaussian_sigma || val <= 0.0f || val != val) return DH_OK;   // prediction.rs:321-323
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    p->params.gaussian_sigma = val;
+    return build_kernel_table(p);
+}
+extern "C" int dh_predictor_sigma(const dh_predictor *p, float *out) {
+    if (!p || !out) return fail(DH_EINVAL, "NULL argument");
+    *out = p->params.gaussian_sigma;
+    return DH_OK;
+}
+
+// Tile of PX x PY window positions per workgroup: as many positions as fit the LDS budget
+// (SAT footprint + leaf ids), at most 1024 (one thread per position in the gate phase).
+static int choose_tile(const dh_predictor *p, Geom &g) {
+    const int step = (int)p->params.stepwidth, sw = (int)p->params.subimage_width, sh = (int)p->params.subimage_height;
+    size_t budget = 100 * 1024;
+    if (const char *e = getenv("DH_LDS_BUDGET_KB")) budget = (size_t)atoi(e) * 1024;
+    budget = std::min<size_t>(budget, 158 * 1024);
+    int fx = 0, fy = 0;
+    if (const char *e = getenv("DH_TILE")) sscanf(e, "%d,%d", &fx, &fy);
+    long best = -1;
+    for (int py = 1; py <= std::min(g.ny, 64); ++py)
+        for (int px = 1; px <= std::min(g.nx, 64); ++px) {
+            if (px * py > 1024) continue;
+            if (fx > 0 && fy > 0 && (px != std::min(fx, g.nx) || py != std::min(fy, g.ny))) continue;
+            size_t lds = dh_traverse_lds_bytes(px, py, step, sw, sh, (int)p->n_trees);
+            if (lds > budget && !(fx > 0 && lds <= 158 * 1024)) continue;
+            long score = (long)px * py * 1000 - labs((long)px - py);
+            if (score > best) { best = score; g.px = px; g.py = py; g.lds = lds; }
+        }
+    if (best < 0) {
+        // a single position must always fit
+        g.px = g.py = 1;
+        g.lds = dh_traverse_lds_bytes(1, 1, step, sw, sh, (int)p->n_trees);
+        if (g.lds > 158 * 1024) return fail(DH_ESIZE, "patch %dx%d with %u trees does not fit LDS", sw, sh, p->n_trees);
+    }
+    g.tiles_x = (g.nx + g.px - 1) / g.px;
+    g.tiles_y = (g.ny + g.py - 1) / g.py;
+    g.ss_max = ((g.px - 1) * step + sw + 1) * ((g.py - 1) * step + sh + 1);
+    return DH_OK;
+}
+
+static int reserve(dh_predictor *p, int n, int w, int h) {
+    if (n <= 0) return fail(DH_EINVAL, "batch size must be positive");
+    Geom g;
+    g.w = w; g.h = h;
+    int rc = patch_grid(p->params, w, h, &g.nx, &g.ny);
+    if (rc) return rc;
+    g.npatch = g.nx * g.ny;
+    bool same_geom = p->geom.w == w && p->geom.h == h;
+    bool dbg_ok = !p->debug || p->dbg_leaf;
+    if (same_geom && n <= p->cap_frames && dbg_ok) return DH_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    int cap = std::max(n, same_geom ? p->cap_frames : 0);
+    free_workspace(p);
+    if (g.npatch > 0) { rc = choose_tile(p, g); if (rc) return rc; }
+    size_t hits_cap = std::max<size_t>((size_t)g.npatch * p->n_trees, 1);
+    if (hits_cap > 0xffffffffull) return fail(DH_ESIZE, "too many (patch, tree) pairs per frame");
+    p->hits_cap = (uint32_t)hits_cap;
+#define STEP(x) if (rc == DH_OK) rc = (x)
+    STEP(dev_alloc(p, &p->hits, (size_t)cap * hits_cap));
+    STEP(dev_alloc(p, &p->counters, (size_t)cap * (1 + DH_POSGRID + DH_GRID3)));
+    STEP(dev_alloc(p, &p->ws_poses, cap));
+    STEP(dev_alloc(p, &p->ws_midp, (size_t)cap * 3));
+    STEP(dev_alloc(p, &p->ws_rot, (size_t)cap * 3));
+    STEP(dev_alloc(p, &p->ws_mask, cap));
+    if (p->debug) {
+        STEP(dev_alloc(p, &p->dbg_leaf, (size_t)cap * std::max(g.npatch, 1) * p->n_trees));
+        STEP(dev_alloc(p, &p->dbg_flags, (size_t)cap * std::max(g.npatch, 1)));
+        STEP(dev_alloc(p, &p->dbg_guess, (size_t)cap * 6));
+        STEP(dev_alloc(p, &p->dbg_trace, (size_t)2 * cap * (p->params.meanshift_iterations + 1) * 3));
+        STEP(dev_alloc(p, &p->dbg_steps, (size_t)2 * cap));
+        STEP(dev_alloc(p, &p->dbg_vcount, 1));
+    }
+#undef STEP
+    if (rc != DH_OK) { free_workspace(p); return rc; }
+    p->geom = g;
+    p->cap_frames = cap;
+    return DH_OK;
+}
+
+extern "C" int dh_predictor_reserve(dh_predictor *p, int n, int w, int h) {
+    if (!p) return fail(DH_EINVAL, "NULL predictor");
+    return reserve(p, n, w, h);
+}
+
+extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                                       const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
+                                       dh_pose *out, void *stream_) {
+    if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_batch_device: NULL argument");
+    if (n == 0) return DH_OK;
+    int rc = reserve(p, n, w, h);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream_;
+    const Geom &g = p->geom;
+    const int N = n;
+    uint32_t *hit_count = p->counters;
+    uint32_t *pos_grid = p->counters + p->cap_frames;
+    uint32_t *rot_grid = pos_grid + (size_t)p->cap_frames * DH_POSGRID;
+
+    HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3) * sizeof(uint32_t), s));
+
+    float kinv[9];
+    mat3_inv_f32(K, kinv);   // cached in a RefCell by the reference (types.rs:436-441)
+
+    if (p->profiling) HIP_TRY(hipEventRecord(p->ev[0], s));
+    if (g.npatch > 0) {
+        TraverseArgs ta{};
+        ta.frames = frames; ta.n_frames = N; ta.w = w; ta.h = h;
+        ta.step = (int)p->params.stepwidth; ta.sw = (int)p->params.subimage_width; ta.sh = (int)p->params.subimage_height;
+        ta.lw = ta.sw / 2; ta.lh = ta.sh / 2;
+        ta.nx = g.nx; ta.ny = g.ny; ta.px = g.px; ta.py = g.py; ta.tiles_x = g.tiles_x; ta.tiles_y = g.tiles_y;
+        ta.ss_max = g.ss_max;
+        memcpy(ta.kinv, kinv, sizeof kinv);
+        ta.f = p->dev;
+        ta.hits = p->hits; ta.hit_count = hit_count; ta.hits_cap = p->hits_cap;
+        ta.dbg_leaf = p->debug ? p->dbg_leaf : nullptr;
+        ta.dbg_flags = p->debug ? p->dbg_flags : nullptr;
+        HIP_TRY(dh_launch_traverse(ta, g.lds, s));
+    }
+    if (p->profiling) HIP_TRY(hipEventRecord(p->ev[1], s));
+    {
+        VoteArgs va{};
+        va.n_frames = N; va.w = w; va.h = h;
+        memcpy(va.k, K, sizeof va.k);
+        va.f = p->dev; va.hits = p->hits; va.hit_count = hit_count; va.hits_cap = p->hits_cap;
+        va.pos_grid = pos_grid; va.rot_grid = rot_grid;
+        HIP_TRY(dh_launch_vote(va, s));
+    }
+    if (p->profiling) HIP_TRY(hipEventRecord(p->ev[2], s));
+    {
+        ClusterArgs ca{};
+        ca.frames = frames; ca.n_frames = N; ca.w = w; ca.h = h;
+        memcpy(ca.kinv, kinv, sizeof kinv);
+        ca.f = p->dev; ca.hits = p->hits; ca.hit_count = hit_count; ca.hits_cap = p->hits_cap;
+        ca.pos_grid = pos_grid; ca.rot_grid = rot_grid; ca.kern_ord = p->kern_ord;
+        ca.iterations = p->params.meanshift_iterations;
+        ca.midp_guess = midp_guess; ca.rot_guess = rot_guess; ca.guess_mask = guess_mask;
+        ca.out = out;
+        if (p->debug) { ca.dbg_guess = p->dbg_guess; ca.dbg_trace = p->dbg_trace; ca.dbg_steps = p->dbg_steps; }
+        HIP_TRY(dh_launch_cluster(ca, s));
+    }
+    if (p->profiling) { HIP_TRY(hipEventRecord(p->ev[3], s)); p->ev_valid = true; }
+    p->last_n = N;
+    p->last_frames = frames;
+    p->dbg_valid = p->debug;
+    return DH_OK;
+}
+
+extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                                const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out) {
+    if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_batch: NULL argument");
+    if (n == 0) return DH_OK;
+    if (n < 0) return fail(DH_EINVAL, "negative batch size");
+    int rc = reserve(p, n, w, h);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(p->device));
+    size_t fbytes = (size_t)n * w * h * sizeof(uint16_t);
+    if (fbytes > p->ws_frames_bytes) {
+        HIP_TRY(hipStreamSynchronize(p->own_stream));
+        if (p->ws_frames) (void)hipFree(p->ws_frames);
+        p->ws_frames = nullptr; p->ws_frames_bytes = 0;
+        size_t want = (size_t)p->cap_frames * w * h * sizeof(uint16_t);
+        rc = dev_alloc(p, &p->ws_frames, want / sizeof(uint16_t));
+        if (rc) return rc;
+        p->ws_frames_bytes = want;
+    }
+    hipStream_t s = p->own_stream;
+    HIP_TRY(hipMemcpyAsync(p->ws_frames, frames, fbytes, hipMemcpyHostToDevice, s));
+    if (midp_guess) HIP_TRY(hipMemcpyAsync(p->ws_midp, midp_guess, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+    if (rot_guess) HIP_TRY(hipMemcpyAsync(p->ws_rot, rot_guess, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (guess_mask) HIP_TRY(hipMemcpyAsync(p->ws_mask, guess_mask, (size_t)n, hipMemcpyHostToDevice, s));
+    rc = dh_predict_batch_device(p, p->ws_frames, n, w, h, K, midp_guess ? p->ws_midp : nullptr,
+                                 rot_guess ? p->ws_rot : nullptr, guess_mask ? p->ws_mask : nullptr, p->ws_poses, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, p->ws_poses, (size_t)n * sizeof(dh_pose), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DH_OK;
+}
+
+// ------------------------------------------------------------------ profiling
+extern "C" int dh_set_profiling(dh_predictor *p, int on) {
+    if (!p) return fail(DH_EINVAL, "NULL predictor");
+    p->profiling = on != 0;
+    p->ev_valid = false;
+    return DH_OK;
+}
+extern "C" int dh_get_timing(dh_predictor *p, dh_timing *out) {
+    if (!p || !out) return fail(DH_EINVAL, "NULL argument");
+    if (!p->ev_valid) return fail(DH_ESTATE, "no profiled batch yet (dh_set_profiling + a batch)");
+    HIP_TRY(hipEventSynchronize(p->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&out->traverse_ms, p->ev[0], p->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&out->vote_ms, p->ev[1], p->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&out->cluster_ms, p->ev[2], p->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&out->total_ms, p->ev[0], p->ev[3]));
+    out->n_frames = (uint32_t)p->last_n;
+    out->reserved = 0;
+    return DH_OK;
+}
+
+// ------------------------------------------------------------------ parity taps
+extern "C" int dh_debug_enable(dh_predictor *p, int on) {
+    if (!p) return fail(DH_EINVAL, "NULL predictor");
+    p->debug = on != 0;
+    if (!p->debug) p->dbg_valid = false;
+    return DH_OK;
+}
+static int tap_ready(dh_predictor *p) {
+    if (!p) return fail(DH_EINVAL, "NULL predictor");
+    if (p->last_n == 0) return fail(DH_ESTATE, "no batch has run on this predictor");
+    hipError_t e = hipSetDevice(p->device);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(DH_EHIP, "sync: %s", hipGetErrorString(e));
+    return DH_OK;
+}
+static int tap_ready_dbg(dh_predictor *p) {
+    int rc = tap_ready(p);
+    if (rc) return rc;
+    if (!p->dbg_valid) return fail(DH_ESTATE, "debug taps were not enabled for the last batch");
+    return DH_OK;
+}
+extern "C" int dh_debug_leaf_indices(dh_predictor *p, int32_t *out, size_t cap) {
+    int rc = tap_ready_dbg(p);
+    if (rc) return rc;
+    size_t n = (size_t)p->last_n * p->geom.npatch * p->n_trees;
+    if (!out || cap < n) return fail(DH_EINVAL, "buffer too small: need %zu elements", n);
+    if (n) HIP_TRY(hipMemcpy(out, p->dbg_leaf, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return DH_OK;
+}
+extern "C" int dh_debug_patch_flags(dh_predictor *p, uint8_t *out, size_t cap) {
+    int rc = tap_ready_dbg(p);
+    if (rc) return rc;
+    size_t n = (size_t)p->last_n * p->geom.npatch;
+    if (!out || cap < n) return fail(DH_EINVAL, "buffer too small: need %zu elements", n);
+    if (n) HIP_TRY(hipMemcpy(out, p->dbg_flags, n, hipMemcpyDeviceToHost));
+    return DH_OK;
+}
+extern "C" int dh_debug_grids(dh_predictor *p, uint32_t *pos_grid, uint32_t *rot_grid) {
+    int rc = tap_ready(p);
+    if (rc) return rc;
+    const uint32_t *pg = p->counters + p->cap_frames, *rg = pg + (size_t)p->cap_frames * DH_POSGRID;
+    if (pos_grid) HIP_TRY(hipMemcpy(pos_grid, pg, (size_t)p->last_n * DH_POSGRID * 4, hipMemcpyDeviceToHost));
+    if (rot_grid) HIP_TRY(hipMemcpy(rot_grid, rg, (size_t)p->last_n * DH_GRID3 * 4, hipMemcpyDeviceToHost));
+    return DH_OK;
+}
+extern "C" int dh_debug_hit_counts(dh_predictor *p, uint32_t *out) {
+    int rc = tap_ready(p);
+    if (rc) return rc;
+    if (!out) return fail(DH_EINVAL, "NULL output");
+    HIP_TRY(hipMemcpy(out, p->counters, (size_t)p->last_n * 4, hipMemcpyDeviceToHost));
+    return DH_OK;
+}
+extern "C" int dh_debug_guesses(dh_predictor *p, int32_t *out) {
+    int rc = tap_ready_dbg(p);
+    if (rc) return rc;
+    if (!out) return fail(DH_EINVAL, "NULL output");
+    HIP_TRY(hipMemcpy(out, p->dbg_guess, (size_t)p->last_n * 6 * 4, hipMemcpyDeviceToHost));
+    return DH_OK;
+}
+extern "C" int dh_debug_meanshift(dh_predictor *p, int which, int32_t *trace, uint32_t *steps) {
+    int rc = tap_ready_dbg(p);
+    if (rc) return rc;
+    if (which < 0 || which > 1) return fail(DH_EINVAL, "which must be 0 or 1");
+    size_t per = (size_t)(p->params.meanshift_iterations + 1) * 3;
+    // device layout is [2][last batch n][...]: the kernel indexed with n_frames = last_n
+    if (trace) HIP_TRY(hipMemcpy(trace, p->dbg_trace + (size_t)which * p->last_n * per, (size_t)p->last_n * per * 4, hipMemcpyDeviceToHost));
+    if (steps) HIP_TRY(hipMemcpy(steps, p->dbg_steps + (size_t)which * p->last_n, (size_t)p->last_n * 4, hipMemcpyDeviceToHost));
+    return DH_OK;
+}
+extern "C" int dh_debug_votes(dh_predictor *p, int frame, int which, int32_t *out, size_t cap, size_t *count) {
+    int rc = tap_ready(p);
+    if (rc) return rc;
+    if (frame < 0 || frame >= p->last_n || which < 0 || which > 1 || !count) return fail(DH_EINVAL, "bad frame / which / count");
+    if (cap > 0xffffffffull) cap = 0xffffffffull;
+    if (!p->dbg_vcount) { rc = dev_alloc(p, &p->dbg_vcount, 1); if (rc) return rc; }
+    if (cap > p->dbg_votes_cap) {
+        if (p->dbg_votes) (void)hipFree(p->dbg_votes);
+        p->dbg_votes = nullptr; p->dbg_votes_cap = 0;
+        rc = dev_alloc(p, &p->dbg_votes, cap * 4);
+        if (rc) return rc;
+        p->dbg_votes_cap = cap;
+    }
+    HIP_TRY(hipMemset(p->dbg_vcount, 0, 4));
+    VotesDumpArgs a{};
+    a.frame = frame; a.which = which; a.f = p->dev; a.hits = p->hits; a.hit_count = p->counters; a.hits_cap = p->hits_cap;
+    a.out = p->dbg_votes; a.cap = (uint32_t)cap; a.count = p->dbg_vcount;
+    HIP_TRY(dh_launch_votes_dump(a, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t c = 0;
+    HIP_TRY(hipMemcpy(&c, p->dbg_vcount, 4, hipMemcpyDeviceToHost));
+    *count = c;
+    size_t ncopy = std::min<size_t>(c, cap);
+    if (ncopy && out) HIP_TRY(hipMemcpy(out, p->dbg_votes, ncopy * 16, hipMemcpyDeviceToHost));
+    return DH_OK;
+}

@@ -1,0 +1,114 @@
+// dh_internal.h -- structures shared by the host runtime (dh_api.hip) and the gfx950 kernels
+// (dh_kernels.hip).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/depthhead_hip.h"
+
+#define DH_GRID 20             // GUESS_GRID_PARTS and the mean-shift kernel edge
+#define DH_GRID3 8000          // 20^3
+#define DH_POSGRID 400         // 20^2
+#define DH_ROTPARTS 120
+
+// leaf_flags bits (written by k_leaf_prepare)
+#define LF_PROB 1u   // prob > 0.0                      (prediction.rs:590)
+#define LF_ROT 2u    // trace(cov(rotations)) <= 400.0  (prediction.rs:600)
+#define LF_OFF 4u    // trace(cov(offsets))  <= 5200.0  (prediction.rs:643)
+
+// Device view of a forest: the flat arrays of dh_forest_desc plus the per-leaf tables that depend
+// only on the leaf (last note) and are computed once by k_leaf_prepare.
+struct DevForest {
+    const int32_t  *roots;
+    const dh_node  *nodes;
+    const double   *leaf_prob;
+    const uint32_t *off_begin;
+    const uint32_t *rot_begin;
+    const float    *offsets;
+    const double   *rotations;
+    uint32_t n_trees, n_nodes, n_leaves, n_off, n_rot;
+    // prepared
+    uint32_t *leaf_v;      // valtoadd                                   (prediction.rs:594-595)
+    uint8_t  *leaf_flags;  // LF_*
+    uint32_t *rot_bin;     // per rotation vote: r1 | r2<<8 | r3<<16      (:605-627)
+    uint16_t *rot_rough;   // per rotation vote: index into the 20^3 grid (:630-636)
+    float    *off_min;     // per leaf, 3 floats: component-wise min of its offsets (-inf if non-finite)
+    float    *off_max;     // per leaf, 3 floats                                     (+inf if non-finite)
+    uint32_t *rbin_box;    // per leaf: min r1|r2<<8|r3<<16 in low 24 bits... see k_leaf_prepare
+    uint32_t *rbin_box_hi; // per leaf: max bins, same packing
+};
+
+// One (gated patch, leaf) pair kept for voting: the patch centre in camera space
+// (prediction.rs:554) and the leaf it reached.
+struct __attribute__((aligned(16))) HitRec {
+    float    p3[3];
+    uint32_t leaf;
+};
+
+struct TraverseArgs {
+    const uint16_t *frames;
+    int n_frames, w, h;
+    int step, sw, sh, lw, lh;
+    int nx, ny;             // patch grid
+    int px, py;             // tile size in patches
+    int tiles_x, tiles_y;
+    int ss_max;             // LDS SAT capacity in words
+    float kinv[9];
+    DevForest f;
+    HitRec   *hits;
+    uint32_t *hit_count;    // [n_frames]
+    uint32_t  hits_cap;     // records per frame
+    int32_t  *dbg_leaf;     // nullable [n][npatch][T]
+    uint8_t  *dbg_flags;    // nullable [n][npatch]
+};
+
+struct VoteArgs {
+    int n_frames, w, h;
+    float k[9];
+    DevForest f;
+    const HitRec   *hits;
+    const uint32_t *hit_count;
+    uint32_t  hits_cap;
+    uint32_t *pos_grid;     // [n][400]
+    uint32_t *rot_grid;     // [n][8000]
+};
+
+struct ClusterArgs {
+    const uint16_t *frames;
+    int n_frames, w, h;
+    float kinv[9];
+    DevForest f;
+    const HitRec   *hits;
+    const uint32_t *hit_count;
+    uint32_t  hits_cap;
+    const uint32_t *pos_grid;
+    const uint32_t *rot_grid;
+    const float    *kern_ord;  // 8000 floats, index (dx*20+dy)*20+dz = summation order (meanshift.rs:344-346)
+    uint32_t  iterations;
+    const float   *midp_guess; // nullable, n*3
+    const double  *rot_guess;  // nullable, n*3
+    const uint8_t *guess_mask; // nullable, n
+    dh_pose  *out;
+    int32_t  *dbg_guess;       // nullable [n][6]
+    int32_t  *dbg_trace;       // nullable [2][n][iterations+1][3]
+    uint32_t *dbg_steps;       // nullable [2][n]
+};
+
+struct VotesDumpArgs {
+    int frame, which;
+    DevForest f;
+    const HitRec   *hits;
+    const uint32_t *hit_count;
+    uint32_t  hits_cap;
+    int32_t  *out;          // cap*4
+    uint32_t  cap;
+    uint32_t *count;
+};
+
+// launchers (dh_kernels.hip)
+hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s);
+hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s);
+hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s);
+hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s);
+hipError_t dh_launch_votes_dump(const VotesDumpArgs &a, hipStream_t s);
+size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees);

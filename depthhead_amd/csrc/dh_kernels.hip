@@ -1,0 +1,744 @@
+// dh_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4: wave64, 160 KB LDS/CU).
+//
+// The hot path of depthhead's HoughPrediction::predict_parameter_parallel
+// (/root/reference src/hough/prediction.rs:397-753) as four kernels:
+//
+//   k_leaf_prepare  once per forest: everything that depends only on a leaf (vote weight, both
+//                   covariance gates, rotation bins, vote bounding boxes)
+//   k_traverse      per batch: summed-area-table tile in LDS -> background gate -> root->leaf walk
+//                   of every (patch, tree) -> probability gate -> (patch, leaf) hit records
+//   k_vote          per batch: coarse 20x20 / 20^3 guess grids from the hit records
+//   k_cluster       per batch: initial guesses + both fixed-iteration Gaussian mean shifts -> pose
+//
+// No MFMA anywhere: there is no dense contraction on this path.  All integer work is exact and
+// order-free (u32 wrapping adds); every floating-point expression is evaluated in the reference's
+// type and order with explicit round-to-nearest intrinsics (no FMA contraction), so results are
+// bit-identical to the CPU restatement in oracle/.
+#include "dh_internal.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------ Rust `as` casts
+// float -> int truncates toward zero, saturates, NaN -> 0.
+__device__ __forceinline__ int32_t f32_as_i32(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+__device__ __forceinline__ int32_t f64_as_i32(double v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0) return INT32_MAX;
+    if (v <= -2147483648.0) return INT32_MIN;
+    return (int32_t)v;
+}
+__device__ __forceinline__ uint64_t f64_as_usize(double v) {
+    if (v != v || v <= 0.0) return 0;
+    if (v >= 18446744073709551616.0) return UINT64_MAX;
+    return (uint64_t)v;
+}
+__device__ __forceinline__ uint64_t f32_as_usize(float v) {
+    if (v != v || v <= 0.0f) return 0;
+    if (v >= 18446744073709551616.0f) return UINT64_MAX;
+    return (uint64_t)v;
+}
+
+// Mat3<f32> * Vec3<f32>: tmp = v0*m[j][0]; tmp = tmp + v_i*m[j][i]   (meancov_estimation.rs:201-216)
+__device__ __forceinline__ void matvec3(const float *m, float v0, float v1, float v2, float r[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float t = __fmul_rn(v0, m[j * 3 + 0]);
+        t = __fadd_rn(t, __fmul_rn(v1, m[j * 3 + 1]));
+        t = __fadd_rn(t, __fmul_rn(v2, m[j * 3 + 2]));
+        r[j] = t;
+    }
+}
+// IntrinsicMatrix::img_to_space_coord (types.rs:432-445)
+__device__ __forceinline__ void to3d(const float *kinv, float px, float py, float z, float out[3]) {
+    float r[3];
+    matvec3(kinv, px, py, 1.0f, r);
+    float c = __fdiv_rn(z, r[2]);
+    out[0] = __fmul_rn(r[0], c);
+    out[1] = __fmul_rn(r[1], c);
+    out[2] = __fmul_rn(r[2], c);
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// ================================================================== k_leaf_prepare
+// One thread per leaf.  Restates prediction.rs:590-636 (per-leaf part) and
+// meancov_estimation.rs:359-378 / :260-265 in the reference's order and types.
+__global__ void __launch_bounds__(256) k_leaf_prepare(DevForest f) {
+    uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= f.n_leaves) return;
+    double prob = f.leaf_prob[L];
+    uint32_t ob = f.off_begin[L], oe = f.off_begin[L + 1];
+    uint32_t rb = f.rot_begin[L], re = f.rot_begin[L + 1];
+    uint32_t n_off = oe - ob, n_rot = re - rb;
+    uint32_t flags = 0, v = 0;
+    float omin[3] = {INFINITY, INFINITY, INFINITY}, omax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t bmin[3] = {255, 255, 255}, bmax[3] = {0, 0, 0};
+    if (prob > 0.0 && n_off > 0 && n_rot > 0) {
+        flags |= LF_PROB;
+        v = (uint32_t)(f64_as_usize(__dmul_rn(1000.0, prob)) / (uint64_t)n_off);   // :594-595
+
+        // ---- rotations, f64 (:600)
+        {
+            const double *s = f.rotations + (size_t)rb * 3;
+            double mu[3] = {s[0], s[1], s[2]};
+            for (uint32_t i = 1; i < n_rot; ++i)
+                for (int k = 0; k < 3; ++k) mu[k] = __dadd_rn(mu[k], s[i * 3 + k]);
+            double dn = (double)n_rot;
+            for (int k = 0; k < 3; ++k) mu[k] = __ddiv_rn(mu[k], dn);
+            double c0 = 0, c1 = 0, c2 = 0;  // only the diagonal feeds the trace
+            for (uint32_t i = 0; i < n_rot; ++i) {
+                double d0 = __dsub_rn(s[i * 3 + 0], mu[0]), d1 = __dsub_rn(s[i * 3 + 1], mu[1]),
+                       d2 = __dsub_rn(s[i * 3 + 2], mu[2]);
+                double q0 = __dmul_rn(d0, d0), q1 = __dmul_rn(d1, d1), q2 = __dmul_rn(d2, d2);
+                if (i == 0) { c0 = q0; c1 = q1; c2 = q2; }
+                else { c0 = __dadd_rn(c0, q0); c1 = __dadd_rn(c1, q1); c2 = __dadd_rn(c2, q2); }
+            }
+            double dn1 = (double)(n_rot - 1);
+            c0 = __ddiv_rn(c0, dn1); c1 = __ddiv_rn(c1, dn1); c2 = __ddiv_rn(c2, dn1);
+            double tr = __dadd_rn(__dadd_rn(__dadd_rn(0.0, c0), c1), c2);
+            if (tr <= DH_MAX_VARIANCE_ROT) flags |= LF_ROT;
+        }
+        // ---- offsets, f32; `/ n as f64` divides by (n as f64) as f32 (meancov_estimation.rs:290-297)
+        {
+            const float *s = f.offsets + (size_t)ob * 3;
+            float mu[3] = {s[0], s[1], s[2]};
+            for (uint32_t i = 1; i < n_off; ++i)
+                for (int k = 0; k < 3; ++k) mu[k] = __fadd_rn(mu[k], s[i * 3 + k]);
+            float dn = (float)(double)n_off;
+            for (int k = 0; k < 3; ++k) mu[k] = __fdiv_rn(mu[k], dn);
+            float c0 = 0, c1 = 0, c2 = 0;
+            for (uint32_t i = 0; i < n_off; ++i) {
+                float d0 = __fsub_rn(s[i * 3 + 0], mu[0]), d1 = __fsub_rn(s[i * 3 + 1], mu[1]),
+                      d2 = __fsub_rn(s[i * 3 + 2], mu[2]);
+                float q0 = __fmul_rn(d0, d0), q1 = __fmul_rn(d1, d1), q2 = __fmul_rn(d2, d2);
+                if (i == 0) { c0 = q0; c1 = q1; c2 = q2; }
+                else { c0 = __fadd_rn(c0, q0); c1 = __fadd_rn(c1, q1); c2 = __fadd_rn(c2, q2); }
+            }
+            float dn1 = (float)(double)(n_off - 1);
+            c0 = __fdiv_rn(c0, dn1); c1 = __fdiv_rn(c1, dn1); c2 = __fdiv_rn(c2, dn1);
+            float tr = __fadd_rn(__fadd_rn(__fadd_rn(0.0f, c0), c1), c2);
+            if (tr <= DH_MAX_VARIANCE_OFFSET) flags |= LF_OFF;
+            bool finite = true;
+            for (uint32_t i = 0; i < n_off; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    float o = s[i * 3 + k];
+                    if (!(fabsf(o) <= 3.0e38f)) finite = false;
+                    omin[k] = fminf(omin[k], o);
+                    omax[k] = fmaxf(omax[k], o);
+                }
+            if (!finite)
+                for (int k = 0; k < 3; ++k) { omin[k] = -INFINITY; omax[k] = INFINITY; }
+        }
+    }
+    // ---- rotation bins (:605-632); host validation guarantees [0,120) for leaves that can vote
+    for (uint32_t i = rb; i < re; ++i) {
+        uint32_t packed = 0, rough = 0, mul = 1;
+        for (int k = 0; k < 3; ++k) {
+            int32_t r = f64_as_i32(__ddiv_rn(__dmul_rn(f.rotations[(size_t)i * 3 + k], 120.0), 360.0)) + 60;
+            if (r >= DH_ROTPARTS) r -= DH_ROTPARTS;
+            else if (r < 0) r += DH_ROTPARTS;
+            uint32_t ru = (uint32_t)r;
+            uint32_t rg = ru * DH_GRID / DH_ROTPARTS;
+            uint32_t rc = ru > 255u ? 255u : ru;    // only reachable for leaves that never vote
+            packed |= rc << (8 * k);
+            rough += (rg < DH_GRID ? rg : 0u) * mul;
+            mul *= DH_GRID;
+            if (rc < bmin[k]) bmin[k] = rc;
+            if (rc > bmax[k]) bmax[k] = rc;
+        }
+        f.rot_bin[i] = packed;
+        f.rot_rough[i] = (uint16_t)rough;   // x + 20*y + 400*z (meanshift.rs:78-88)
+    }
+    f.leaf_v[L] = v;
+    f.leaf_flags[L] = (uint8_t)flags;
+    for (int k = 0; k < 3; ++k) { f.off_min[L * 3 + k] = omin[k]; f.off_max[L * 3 + k] = omax[k]; }
+    f.rbin_box[L] = bmin[0] | (bmin[1] << 8) | (bmin[2] << 16);
+    f.rbin_box_hi[L] = bmax[0] | (bmax[1] << 8) | (bmax[2] << 16);
+}
+
+hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s) {
+    if (f.n_leaves == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_leaf_prepare, dim3((f.n_leaves + 255) / 256), dim3(256), 0, s, f);
+    return hipGetLastError();
+}
+
+// ================================================================== k_traverse
+// One 1024-thread workgroup per tile of PX x PY sliding-window positions of one frame.
+//
+// LDS: [ SAT (fh+1)x(fw+1) u32 | leaf ids npt*T i32 | p3 npt*3 f32 | active list npt u32 | misc ]
+//
+// The summed-area table is kept modulo 2^32: any rectangle inside a patch sums to
+// < sw*sh*65535 < 2^32 (checked at predictor creation), so differences are exact and one rect
+// mean costs 4 LDS reads instead of the reference's O(area) pixel loop (types.rs:317-339).
+#define TRAV_THREADS 1024
+#define TRAV_WAVES (TRAV_THREADS / WAVE)
+
+size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees) {
+    size_t fw = (size_t)(px - 1) * step + sw, fh = (size_t)(py - 1) * step + sh;
+    size_t npt = (size_t)px * py;
+    return ((fw + 1) * (fh + 1) + npt * n_trees + npt * 3 + npt + 16) * 4;
+}
+
+__global__ void __launch_bounds__(TRAV_THREADS) k_traverse(TraverseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int T = (int)a.f.n_trees;
+
+    // XCD-aware block -> (frame, tile): blocks b and b+8 share an XCD (and its L2), so one XCD
+    // walks whole frames and the overlapping tile halos of a frame are re-read from one L2.
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int frame = (j / tiles) * 8 + xcd;
+    const int tile = j % tiles;
+    if (frame >= a.n_frames) return;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int cx = min(a.px, a.nx - tx * a.px), cy = min(a.py, a.ny - ty * a.py);
+    const int npt = cx * cy;
+    const int fx0 = tx * a.px * a.step, fy0 = ty * a.py * a.step;   // footprint origin (pixels)
+    const int fw = (cx - 1) * a.step + a.sw, fh = (cy - 1) * a.step + a.sh;
+    const int ss = fw + 1;
+
+    uint32_t *sat = lds;
+    int32_t *leaf = (int32_t *)(lds + a.ss_max);
+    float *p3s = (float *)(leaf + a.px * a.py * T);
+    uint32_t *active = (uint32_t *)(p3s + a.px * a.py * 3);
+    uint32_t *misc = active + a.px * a.py;   // [0] n_active, [1] queue head, [2] hit total, [3] hit base
+
+    const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
+
+    // ---- phase 1a: row prefix sums, one wave per row, 4 pixels per lane
+    if (tid < 4) misc[tid] = 0;
+    for (int i = tid; i < ss; i += TRAV_THREADS) sat[i] = 0;          // row 0
+    for (int r = wave; r < fh; r += TRAV_WAVES) {
+        const uint16_t *row = img + (size_t)(fy0 + r) * a.w + fx0;
+        uint32_t *dst = sat + (r + 1) * ss;
+        if (lane == 0) dst[0] = 0;                                     // column 0
+        uint32_t carry = 0;
+        for (int x0 = 0; x0 < fw; x0 += WAVE * 4) {
+            int x = x0 + lane * 4;
+            uint32_t p0 = x + 0 < fw ? row[x + 0] : 0u, p1 = x + 1 < fw ? row[x + 1] : 0u,
+                     p2 = x + 2 < fw ? row[x + 2] : 0u, p3 = x + 3 < fw ? row[x + 3] : 0u;
+            uint32_t s0 = p0, s1 = s0 + p1, s2 = s1 + p2, s3 = s2 + p3;
+            uint32_t incl = s3;                                        // wave inclusive scan of lane totals
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            uint32_t base = carry + incl - s3;
+            if (x + 0 < fw) dst[x + 1] = base + s0;
+            if (x + 1 < fw) dst[x + 2] = base + s1;
+            if (x + 2 < fw) dst[x + 3] = base + s2;
+            if (x + 3 < fw) dst[x + 4] = base + s3;
+            carry += __shfl(incl, WAVE - 1);
+        }
+    }
+    __syncthreads();
+    // ---- phase 1b: column prefix sums, one thread per column
+    for (int x = 1 + tid; x <= fw; x += TRAV_THREADS) {
+        uint32_t run = 0;
+        uint32_t *col = sat + x;
+#pragma unroll 8
+        for (int y = 1; y <= fh; ++y) {
+            run += col[y * ss];
+            col[y * ss] = run;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: per patch: centre -> 3-D (prediction.rs:551-554), background gate (:567-571)
+    for (int p = tid; p < npt; p += TRAV_THREADS) {
+        int pxi = p % cx, pyi = p / cx;
+        int ox = pxi * a.step, oy = pyi * a.step;                      // patch origin inside the footprint
+        uint32_t sum = sat[(oy + a.sh) * ss + ox + a.sw] - sat[oy * ss + ox + a.sw] -
+                       sat[(oy + a.sh) * ss + ox] + sat[oy * ss + ox];
+        int gx = fx0 + ox + a.lw, gy = fy0 + oy + a.lh;                // window centre (x, y)
+        float z = (float)img[(size_t)gy * a.w + gx];
+        float q[3];
+        to3d(a.kinv, (float)gx, (float)gy, z, q);
+        p3s[p * 3 + 0] = q[0]; p3s[p * 3 + 1] = q[1]; p3s[p * 3 + 2] = q[2];
+        bool nonbg = sum != 0;   // (sum as f64)/(count as f64) > 0.0  <=>  sum > 0
+        if (nonbg) active[atomicAdd(&misc[0], 1u)] = (uint32_t)p;
+        if (a.dbg_flags) {
+            int gp = (ty * a.py + pyi) * a.nx + tx * a.px + pxi;
+            a.dbg_flags[(size_t)frame * a.nx * a.ny + gp] = nonbg ? 1 : 0;
+            if (!nonbg && a.dbg_leaf)
+                for (int t = 0; t < T; ++t) a.dbg_leaf[((size_t)frame * a.nx * a.ny + gp) * T + t] = -1;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: root->leaf walks.  Work item i = (tree i / n_active, active slot i % n_active), so
+    // the lanes of a wave start in the same tree and share its top-level nodes.  Lanes whose walk
+    // ended are refilled from a workgroup queue: one ballot finds them, one LDS atomic per wave
+    // reserves that many items, each lane takes base + (its rank among the refilling lanes).
+    // Every lane leaves the loop once the queue is exhausted and its own walk hit a leaf; trees
+    // are validated acyclic on the host, so every walk ends.
+    const int n_active = (int)misc[0];
+    const int total = n_active * T;
+    {
+        int item = -1;      // -1: needs work, -2: queue exhausted
+        int cur = 0, pbase = 0, lslot = 0;
+        for (;;) {
+            bool need = item == -1;
+            uint64_t m = __ballot(need);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = (int)atomicAdd(&misc[1], (uint32_t)__popcll(m));
+                base = __shfl(base, 0);
+                if (need) {
+                    int k = base + __popcll(m & lanemask_lt());
+                    if (k < total) {
+                        int t = k / n_active, slot = k - t * n_active;
+                        int p = (int)active[slot];
+                        int pxi = p % cx, pyi = p / cx;
+                        pbase = pyi * a.step * ss + pxi * a.step;
+                        lslot = p * T + t;
+                        cur = a.f.roots[t];
+                        item = k;
+                        if (cur < 0) { leaf[lslot] = ~cur; item = -1; }   // single-leaf tree
+                    } else {
+                        item = -2;
+                    }
+                }
+            }
+            if (__ballot(item >= 0) == 0ull) {
+                if (__ballot(item == -1) == 0ull) break;   // all lanes exhausted
+                continue;                                   // some lane refills next round
+            }
+            if (item >= 0) {
+                // HoughTreeFunctions::binarize (houghforest.rs:185-193) with O(1) rect sums
+                const uint4 *np = (const uint4 *)(a.f.nodes + cur);
+                uint4 n0 = np[0], n1 = np[1];
+                int ax0 = n0.x & 0xffff, ay0 = n0.x >> 16, ax1 = n0.y & 0xffff, ay1 = n0.y >> 16;
+                int bx0 = n0.z & 0xffff, by0 = n0.z >> 16, bx1 = n0.w & 0xffff, by1 = n0.w >> 16;
+                double thr = __hiloint2double((int)n1.y, (int)n1.x);
+                const uint32_t *sp = sat + pbase;
+                uint32_t s1 = sp[ay1 * ss + ax1] - sp[ay0 * ss + ax1] - sp[ay1 * ss + ax0] + sp[ay0 * ss + ax0];
+                uint32_t s2 = sp[by1 * ss + bx1] - sp[by0 * ss + bx1] - sp[by1 * ss + bx0] + sp[by0 * ss + bx0];
+                uint32_t c1 = (uint32_t)((ax1 - ax0) * (ay1 - ay0)), c2 = (uint32_t)((bx1 - bx0) * (by1 - by0));
+                double a1 = c1 ? __ddiv_rn((double)s1, (double)c1) : 0.0;   // types.rs:335-338
+                double a2 = c2 ? __ddiv_rn((double)s2, (double)c2) : 0.0;
+                bool one = __dsub_rn(a1, a2) > thr;
+                cur = one ? (int)n1.w : (int)n1.z;
+                if (cur < 0) { leaf[lslot] = ~cur; item = -1; }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4: mean leaf probability in tree order (prediction.rs:582-584), hit records
+    uint32_t my_hits = 0, my_base = 0;
+    int my_p = -1;
+    bool gated = false;
+    if (tid < n_active) {
+        my_p = (int)active[tid];
+        double prob = 0.0;
+        for (int t = 0; t < T; ++t) prob = __dadd_rn(prob, a.f.leaf_prob[leaf[my_p * T + t]]);
+        prob = __ddiv_rn(prob, (double)T);
+        gated = prob > DH_PROB_GATE;
+        if (gated)
+            for (int t = 0; t < T; ++t) {
+                uint32_t lf = a.f.leaf_flags[leaf[my_p * T + t]];
+                if ((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF))) my_hits++;
+            }
+        if (my_hits) my_base = atomicAdd(&misc[2], my_hits);
+        if (a.dbg_flags) {
+            int pxi = my_p % cx, pyi = my_p / cx;
+            int gp = (ty * a.py + pyi) * a.nx + tx * a.px + pxi;
+            size_t o = (size_t)frame * a.nx * a.ny + gp;
+            if (gated) a.dbg_flags[o] = 3;
+            if (a.dbg_leaf)
+                for (int t = 0; t < T; ++t) a.dbg_leaf[o * T + t] = leaf[my_p * T + t];
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && misc[2]) misc[3] = atomicAdd(&a.hit_count[frame], misc[2]);
+    __syncthreads();
+    if (my_hits) {
+        uint32_t o = misc[3] + my_base;
+        HitRec *dst = a.hits + (size_t)frame * a.hits_cap;
+        float q0 = p3s[my_p * 3 + 0], q1 = p3s[my_p * 3 + 1], q2 = p3s[my_p * 3 + 2];
+        for (int t = 0; t < T; ++t) {
+            uint32_t lid = (uint32_t)leaf[my_p * T + t];
+            uint32_t lf = a.f.leaf_flags[lid];
+            if ((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF))) {
+                if (o < a.hits_cap) {
+                    float4 rec = make_float4(q0, q1, q2, __uint_as_float(lid));
+                    *(float4 *)(dst + o) = rec;
+                }
+                o++;
+            }
+        }
+    }
+}
+
+hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_traverse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int frames8 = (a.n_frames + 7) / 8 * 8;
+    int grid = frames8 * a.tiles_x * a.tiles_y;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_traverse, dim3(grid), dim3(TRAV_THREADS), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+// ================================================================== k_vote
+// Coarse guess grids (prediction.rs:529-533, :630-636, :661-676).  Each workgroup owns a slice of
+// one frame's hit records, accumulates in LDS and flushes its non-zero cells with integer atomics
+// (exact, order-free, wrapping like the reference's release-mode u32 `+=`).
+#define VOTE_THREADS 256
+#define VOTE_SLICES 8
+
+__global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
+    __shared__ uint32_t pos[DH_POSGRID];
+    __shared__ uint32_t rot[DH_GRID3];
+    const int frame = blockIdx.y, tid = threadIdx.x;
+    uint32_t n = a.hit_count[frame];
+    if (n > a.hits_cap) n = a.hits_cap;
+    const uint32_t per = (n + VOTE_SLICES - 1) / VOTE_SLICES;
+    const uint32_t h0 = blockIdx.x * per, h1 = min(n, h0 + per);
+    if (h0 >= h1) return;
+    for (int i = tid; i < DH_POSGRID; i += VOTE_THREADS) pos[i] = 0;
+    for (int i = tid; i < DH_GRID3; i += VOTE_THREADS) rot[i] = 0;
+    __syncthreads();
+    const HitRec *hits = a.hits + (size_t)frame * a.hits_cap;
+    const float wm1 = (float)(a.w - 1), hm1 = (float)(a.h - 1);
+    for (uint32_t i = h0 + tid; i < h1; i += VOTE_THREADS) {
+        float4 rec = *(const float4 *)(hits + i);
+        uint32_t L = __float_as_uint(rec.w);
+        uint32_t lf = a.f.leaf_flags[L], v = a.f.leaf_v[L];
+        if (lf & LF_ROT) {
+            uint32_t rb = a.f.rot_begin[L], re = a.f.rot_begin[L + 1];
+            for (uint32_t r = rb; r < re; ++r) atomicAdd(&rot[a.f.rot_rough[r]], v);      // :636
+        }
+        if (lf & LF_OFF) {
+            uint32_t ob = a.f.off_begin[L], oe = a.f.off_begin[L + 1];
+            for (uint32_t o = ob; o < oe; ++o) {
+                const float *of = a.f.offsets + (size_t)o * 3;
+                float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // :647
+                if (nz < 0.0f) continue;                                                  // :650
+                float r[3];
+                matvec3(a.k, nx, ny, nz, r);                                              // types.rs:425
+                float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
+                float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;               // :662
+                float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;               // :663
+                uint64_t gx = f32_as_usize(x2) * DH_GRID / (uint64_t)a.w;                  // :671-672
+                uint64_t gy = f32_as_usize(y2) * DH_GRID / (uint64_t)a.h;
+                atomicAdd(&pos[gy * DH_GRID + gx], v);                                    // :675
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *gp = a.pos_grid + (size_t)frame * DH_POSGRID, *gr = a.rot_grid + (size_t)frame * DH_GRID3;
+    for (int i = tid; i < DH_POSGRID; i += VOTE_THREADS) if (pos[i]) atomicAdd(&gp[i], pos[i]);
+    for (int i = tid; i < DH_GRID3; i += VOTE_THREADS) if (rot[i]) atomicAdd(&gr[i], rot[i]);
+}
+
+hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
+    if (a.n_frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_vote, dim3(VOTE_SLICES, a.n_frames), dim3(VOTE_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+// ================================================================== k_cluster
+// One workgroup per (frame, accumulator): blockIdx.x = 0 head position (`mid`), 1 rotation (`rot`).
+//
+// The reference keeps both accumulators as unbounded HashMap<(i32,i32,i32),u32>
+// (meanshift.rs:14-68) and reads a 20^3 window per iteration.  Here the window is rebuilt per
+// iteration straight from the hit records: every vote whose cell falls inside the window is added
+// to an LDS cell with an integer atomic (exact), leaves whose vote bounding box misses the window
+// are skipped with one test.  The weighted sums are then taken over the non-zero cells in the
+// reference's x -> y -> z order (meanshift.rs:344-381) as a strictly sequential f32 chain
+// (4 lanes: num.x, num.y, num.z, den); everything off that chain (cell compaction, kernel weight,
+// products) is done by all 256 threads.
+#define CL_THREADS 256
+#define CL_WAVES (CL_THREADS / WAVE)
+#define CL_CHUNKS 32            // 32 * 256 = 8192 >= 8000 window cells
+#define CL_PROD_CAP 2048        // products staged per pass (x4 floats = 32 KB)
+
+__device__ __forceinline__ bool window_hits_range(int32_t lo, int32_t hi, int32_t pos) {
+    // exists cell in [lo,hi] and d in [-10,9] with cell == pos + d (i32 wrapping, as the reference's
+    // release-mode `pos + offset`)?
+    uint32_t len = (uint32_t)hi - (uint32_t)lo;
+    uint32_t u = (uint32_t)pos - 10u - (uint32_t)lo;
+    return u <= len || u >= (uint32_t)(-19);
+}
+
+__global__ void __launch_bounds__(CL_THREADS) k_cluster(ClusterArgs a) {
+    __shared__ uint32_t win[CL_CHUNKS * CL_THREADS];
+    __shared__ __attribute__((aligned(16))) float prod[CL_PROD_CAP * 4];
+    __shared__ uint32_t cnt[CL_CHUNKS * CL_WAVES];
+    __shared__ unsigned long long red64[CL_WAVES * 2];
+    __shared__ uint32_t red32[CL_WAVES * 2];
+    __shared__ int32_t s_pos[3];
+    __shared__ float s_acc[4];
+    __shared__ uint32_t s_total;
+
+    const int which = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const uint8_t gmask = a.guess_mask ? a.guess_mask[frame] : 3;
+
+    // ---------------- initial guess
+    if (which == 0) {
+        // first strictly-greatest cell of the 20x20 grid, start (max=0, idx=0) (prediction.rs:694-702)
+        const uint32_t *g = a.pos_grid + (size_t)frame * DH_POSGRID;
+        unsigned long long best = 0;   // (value << 32) | (~idx): max picks greatest value, then smallest idx
+        for (int i = tid; i < DH_POSGRID; i += CL_THREADS) {
+            unsigned long long k = ((unsigned long long)g[i] << 32) | (uint32_t)(~(uint32_t)i);
+            if (g[i] && k > best) best = k;
+        }
+        for (int d = WAVE / 2; d; d >>= 1) { unsigned long long o = __shfl_down(best, d); if (o > best) best = o; }
+        if (lane == 0) red64[wave] = best;
+        __syncthreads();
+        best = red64[0];
+        for (int i = 1; i < CL_WAVES; ++i) if (red64[i] > best) best = red64[i];
+        int best_idx = best ? (int)(~(uint32_t)best) : 0;
+        int gpw = a.w / DH_GRID, gph = a.h / DH_GRID;                 // :706-707
+        int mxg = best_idx % DH_GRID, myg = best_idx / DH_GRID;       // :708-709
+        // mean of the non-zero pixels of that image cell (:711-725)
+        const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
+        unsigned long long zs = 0; uint32_t zc = 0;
+        for (int i = tid; i < gpw * gph; i += CL_THREADS) {
+            int xx = gpw * mxg + i % gpw, yy = gph * myg + i / gpw;
+            uint32_t v = img[(size_t)yy * a.w + xx];
+            if (v) { zs += v; zc++; }
+        }
+        for (int d = WAVE / 2; d; d >>= 1) { zs += __shfl_down(zs, d); zc += __shfl_down(zc, d); }
+        __syncthreads();
+        if (lane == 0) { red64[wave] = zs; red32[wave] = zc; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < CL_WAVES; ++i) { zs += red64[i]; zc += red32[i]; }
+            float meanz = zc ? (float)__ddiv_rn((double)zs, (double)zc) : 0.0f;
+            float mx = __fmul_rn(__fadd_rn((float)mxg, 0.5f), (float)gpw);       // :727-728
+            float my = __fmul_rn(__fadd_rn((float)myg, 0.5f), (float)gph);
+            float q[3];
+            to3d(a.kinv, mx, my, meanz, q);                                       // :729
+            int32_t gm[3] = {f32_as_i32(q[0]), f32_as_i32(q[1]), f32_as_i32(q[2]) / DH_ZSCALEFACTOR};  // :750
+            if (a.midp_guess && (gmask & 1)) {                                    // :437-441
+                const float *mg = a.midp_guess + (size_t)frame * 3;
+                gm[0] = f32_as_i32(mg[0]); gm[1] = f32_as_i32(mg[1]); gm[2] = f32_as_i32(mg[2]) / DH_ZSCALEFACTOR;
+            }
+            s_pos[0] = gm[0]; s_pos[1] = gm[1]; s_pos[2] = gm[2];
+        }
+    } else {
+        // first strictly-greatest non-zero cell in x-fastest order (prediction.rs:733-742, meanshift.rs:114-138)
+        const uint32_t *g = a.rot_grid + (size_t)frame * DH_GRID3;
+        unsigned long long best = 0;
+        for (int i = tid; i < DH_GRID3; i += CL_THREADS) {
+            unsigned long long k = ((unsigned long long)g[i] << 32) | (uint32_t)(~(uint32_t)i);
+            if (g[i] && k > best) best = k;
+        }
+        for (int d = WAVE / 2; d; d >>= 1) { unsigned long long o = __shfl_down(best, d); if (o > best) best = o; }
+        if (lane == 0) red64[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            best = red64[0];
+            for (int i = 1; i < CL_WAVES; ++i) if (red64[i] > best) best = red64[i];
+            uint32_t idx = best ? ~(uint32_t)best : 0u;
+            uint32_t rb[3] = {idx % DH_GRID, (idx / DH_GRID) % DH_GRID, idx / (DH_GRID * DH_GRID)};
+            for (int k = 0; k < 3; ++k) {
+                double deg = __ddiv_rn(__dadd_rn(__dmul_rn((double)rb[k], 360.0), 180.0), 20.0);   // :745-747
+                if (a.rot_guess && (gmask & 2))                                                   // :444-453
+                    deg = __dadd_rn(__ddiv_rn(__dmul_rn(a.rot_guess[(size_t)frame * 3 + k], 180.0), 3.14159), 180.0);
+                s_pos[k] = f64_as_i32(__ddiv_rn(__dmul_rn(deg, 120.0), 360.0));                   // :458-460
+            }
+        }
+    }
+    __syncthreads();
+    int32_t pos[3] = {s_pos[0], s_pos[1], s_pos[2]};
+    if (a.dbg_guess && tid < 3) a.dbg_guess[(size_t)frame * 6 + which * 3 + tid] = pos[tid];
+    int32_t *trace = a.dbg_trace ? a.dbg_trace + ((size_t)which * a.n_frames + frame) * (a.iterations + 1) * 3 : nullptr;
+    if (trace && tid < 3) trace[tid] = pos[tid];
+
+    // ---------------- mean shift (meanshift.rs:328-407)
+    uint32_t n_hits = a.hit_count[frame];
+    if (n_hits > a.hits_cap) n_hits = a.hits_cap;
+    const HitRec *hits = a.hits + (size_t)frame * a.hits_cap;
+    uint32_t steps = 0;
+    for (uint32_t it = 0; it < a.iterations; ++it) {
+        for (int i = tid; i < CL_CHUNKS * CL_THREADS; i += CL_THREADS) win[i] = 0;
+        __syncthreads();
+        // ---- window gather
+        for (uint32_t i = tid; i < n_hits; i += CL_THREADS) {
+            float4 rec = *(const float4 *)(hits + i);
+            uint32_t L = __float_as_uint(rec.w);
+            uint32_t lf = a.f.leaf_flags[L];
+            if (which == 0) {
+                if (!(lf & LF_OFF)) continue;
+                const float *mn = a.f.off_min + (size_t)L * 3, *mx = a.f.off_max + (size_t)L * 3;
+                // cell_k = trunc(p_k - o_k) is monotone in o_k, so it lies in [trunc(p-omax), trunc(p-omin)]
+                if (!window_hits_range(f32_as_i32(__fsub_rn(rec.x, mx[0])), f32_as_i32(__fsub_rn(rec.x, mn[0])), pos[0])) continue;
+                if (!window_hits_range(f32_as_i32(__fsub_rn(rec.y, mx[1])), f32_as_i32(__fsub_rn(rec.y, mn[1])), pos[1])) continue;
+                if (!window_hits_range(f32_as_i32(__fsub_rn(rec.z, mx[2])), f32_as_i32(__fsub_rn(rec.z, mn[2])), pos[2])) continue;
+                uint32_t v = a.f.leaf_v[L];
+                uint32_t ob = a.f.off_begin[L], oe = a.f.off_begin[L + 1];
+                for (uint32_t o = ob; o < oe; ++o) {
+                    const float *of = a.f.offsets + (size_t)o * 3;
+                    float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // prediction.rs:647
+                    if (nz < 0.0f) continue;                                                                      // :650
+                    uint32_t dx = (uint32_t)f32_as_i32(nx) - (uint32_t)pos[0] + 10u;                              // :667
+                    uint32_t dy = (uint32_t)f32_as_i32(ny) - (uint32_t)pos[1] + 10u;
+                    uint32_t dz = (uint32_t)f32_as_i32(__fdiv_rn(nz, (float)DH_ZSCALEFACTOR)) - (uint32_t)pos[2] + 10u;
+                    if (dx < 20u && dy < 20u && dz < 20u) atomicAdd(&win[(dx * 20u + dy) * 20u + dz], v);
+                }
+            } else {
+                if (!(lf & LF_ROT)) continue;
+                uint32_t bl = a.f.rbin_box[L], bh = a.f.rbin_box_hi[L];
+                if (!window_hits_range((int32_t)(bl & 255u), (int32_t)(bh & 255u), pos[0])) continue;
+                if (!window_hits_range((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), pos[1])) continue;
+                if (!window_hits_range((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), pos[2])) continue;
+                uint32_t v = a.f.leaf_v[L];
+                uint32_t rb = a.f.rot_begin[L], re = a.f.rot_begin[L + 1];
+                for (uint32_t r = rb; r < re; ++r) {
+                    uint32_t b = a.f.rot_bin[r];                                                                  // prediction.rs:635
+                    uint32_t dx = (b & 255u) - (uint32_t)pos[0] + 10u;
+                    uint32_t dy = ((b >> 8) & 255u) - (uint32_t)pos[1] + 10u;
+                    uint32_t dz = ((b >> 16) & 255u) - (uint32_t)pos[2] + 10u;
+                    if (dx < 20u && dy < 20u && dz < 20u) atomicAdd(&win[(dx * 20u + dy) * 20u + dz], v);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- order-preserving compaction of the non-zero cells: cell index = chunk*256 + tid
+#pragma unroll 4
+        for (int c = 0; c < CL_CHUNKS; ++c) {
+            uint64_t b = __ballot(win[c * CL_THREADS + tid] != 0);
+            if (lane == 0) cnt[c * CL_WAVES + wave] = (uint32_t)__popcll(b);
+        }
+        __syncthreads();
+        if (wave == 0) {   // exclusive scan of the 128 (chunk, wave) counts, 2 per lane
+            uint32_t c0 = cnt[lane * 2], c1 = cnt[lane * 2 + 1];
+            uint32_t incl = c0 + c1;
+            for (int d = 1; d < WAVE; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            uint32_t ex = incl - (c0 + c1);
+            cnt[lane * 2] = ex; cnt[lane * 2 + 1] = ex + c0;
+            if (lane == WAVE - 1) s_total = incl;
+            if (lane < 4) s_acc[lane] = 0.0f;
+        }
+        __syncthreads();
+        const uint32_t total = s_total;
+        for (uint32_t base = 0; base < total; base += CL_PROD_CAP) {
+#pragma unroll 2
+            for (int c = 0; c < CL_CHUNKS; ++c) {
+                const uint32_t fc = win[c * CL_THREADS + tid];
+                uint64_t b = __ballot(fc != 0);
+                if (fc) {
+                    uint32_t k = cnt[c * CL_WAVES + wave] + (uint32_t)__popcll(b & lanemask_lt());
+                    if (k >= base && k < base + CL_PROD_CAP) {
+                        uint32_t cell = (uint32_t)(c * CL_THREADS + tid);
+                        uint32_t dz = cell % 20u, dy = (cell / 20u) % 20u, dx = cell / 400u;
+                        float w = __fmul_rn(a.kern_ord[cell], (float)fc);                   // meanshift.rs:370-379
+                        float ax = (float)(int32_t)((uint32_t)pos[0] + dx - 10u);           // :373-375
+                        float ay = (float)(int32_t)((uint32_t)pos[1] + dy - 10u);
+                        float az = (float)(int32_t)((uint32_t)pos[2] + dz - 10u);
+                        float4 pr = make_float4(__fmul_rn(ax, w), __fmul_rn(ay, w), __fmul_rn(az, w), w);
+                        *(float4 *)(prod + (k - base) * 4) = pr;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 4) {   // the sequential chain: acc = acc + prod[i], in cell order
+                float acc = s_acc[tid];
+                uint32_t m = min((uint32_t)CL_PROD_CAP, total - base);
+                uint32_t i = 0;
+                for (; i + 8 <= m; i += 8) {
+                    float v0 = prod[(i + 0) * 4 + tid], v1 = prod[(i + 1) * 4 + tid], v2 = prod[(i + 2) * 4 + tid],
+                          v3 = prod[(i + 3) * 4 + tid], v4 = prod[(i + 4) * 4 + tid], v5 = prod[(i + 5) * 4 + tid],
+                          v6 = prod[(i + 6) * 4 + tid], v7 = prod[(i + 7) * 4 + tid];
+                    acc = __fadd_rn(acc, v0); acc = __fadd_rn(acc, v1); acc = __fadd_rn(acc, v2); acc = __fadd_rn(acc, v3);
+                    acc = __fadd_rn(acc, v4); acc = __fadd_rn(acc, v5); acc = __fadd_rn(acc, v6); acc = __fadd_rn(acc, v7);
+                }
+                for (; i < m; ++i) acc = __fadd_rn(acc, prod[i * 4 + tid]);
+                s_acc[tid] = acc;
+            }
+            __syncthreads();
+        }
+        float den = s_acc[3];
+        if (den == 0.0f) break;                                                              // :385-388
+        int32_t np0 = f32_as_i32(__fdiv_rn(s_acc[0], den)), np1 = f32_as_i32(__fdiv_rn(s_acc[1], den)),
+                np2 = f32_as_i32(__fdiv_rn(s_acc[2], den));                                   // :391-394
+        bool fixed = np0 == pos[0] && np1 == pos[1] && np2 == pos[2];
+        pos[0] = np0; pos[1] = np1; pos[2] = np2;
+        steps++;
+        if (trace && tid < 3) trace[steps * 3 + tid] = pos[tid];
+        __syncthreads();   // s_acc / win are rewritten next iteration
+        if (fixed) {
+            // a fixed point: every remaining iteration recomputes the same window and the same
+            // position, so the reference's result (and trace) is this position repeated
+            if (trace && tid < 3)
+                for (uint32_t s2 = steps + 1; s2 <= a.iterations; ++s2) trace[s2 * 3 + tid] = pos[tid];
+            steps = a.iterations;
+            break;
+        }
+    }
+    if (a.dbg_steps && tid == 0) a.dbg_steps[(size_t)which * a.n_frames + frame] = steps;
+    if (tid == 0) {
+        dh_pose *o = a.out + frame;
+        if (which == 0) {                                                                    // prediction.rs:486-488
+            o->mid_point[0] = (float)pos[0];
+            o->mid_point[1] = (float)pos[1];
+            o->mid_point[2] = (float)(int32_t)((uint32_t)pos[2] * (uint32_t)DH_ZSCALEFACTOR);
+            o->reserved = 0;
+        } else {                                                                             // :477-482
+            for (int k = 0; k < 3; ++k)
+                o->rotation[k] = __dmul_rn(__ddiv_rn(__dsub_rn((double)pos[k], 60.0), 60.0), 3.14159);
+        }
+    }
+}
+
+hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s) {
+    if (a.n_frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cluster, dim3(2, a.n_frames), dim3(CL_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+// ================================================================== k_votes_dump (parity tap)
+// Emits every vote of one frame as an (x, y, z, value) record so a test can aggregate them into
+// the full sparse accumulator the reference builds (prediction.rs:635, :667).
+__global__ void __launch_bounds__(256) k_votes_dump(VotesDumpArgs a) {
+    uint32_t n = a.hit_count[a.frame];
+    if (n > a.hits_cap) n = a.hits_cap;
+    const HitRec *hits = a.hits + (size_t)a.frame * a.hits_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 rec = *(const float4 *)(hits + i);
+        uint32_t L = __float_as_uint(rec.w);
+        uint32_t lf = a.f.leaf_flags[L], v = a.f.leaf_v[L];
+        if (a.which == 0 && (lf & LF_OFF)) {
+            for (uint32_t o = a.f.off_begin[L]; o < a.f.off_begin[L + 1]; ++o) {
+                const float *of = a.f.offsets + (size_t)o * 3;
+                float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]);
+                if (nz < 0.0f) continue;
+                uint32_t k = atomicAdd(a.count, 1u);
+                if (k < a.cap) {
+                    a.out[k * 4 + 0] = f32_as_i32(nx); a.out[k * 4 + 1] = f32_as_i32(ny);
+                    a.out[k * 4 + 2] = f32_as_i32(__fdiv_rn(nz, (float)DH_ZSCALEFACTOR)); a.out[k * 4 + 3] = (int32_t)v;
+                }
+            }
+        } else if (a.which == 1 && (lf & LF_ROT)) {
+            for (uint32_t r = a.f.rot_begin[L]; r < a.f.rot_begin[L + 1]; ++r) {
+                uint32_t b = a.f.rot_bin[r];
+                uint32_t k = atomicAdd(a.count, 1u);
+                if (k < a.cap) {
+                    a.out[k * 4 + 0] = (int32_t)(b & 255u); a.out[k * 4 + 1] = (int32_t)((b >> 8) & 255u);
+                    a.out[k * 4 + 2] = (int32_t)((b >> 16) & 255u); a.out[k * 4 + 3] = (int32_t)v;
+                }
+            }
+        }
+    }
+}
+
+hipError_t dh_launch_votes_dump(const VotesDumpArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_votes_dump, dim3(256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

@@ -1,0 +1,215 @@
+"""Seeded synthetic inputs: BIWI-shaped depth frames and Hough forests.
+
+Neither the BIWI data nor the released pretrained forest are available offline (Readme.md:17-45,
+72-74 of the reference), so tests and the bench use these generators.
+Everything is a pure function of the seed (counter-based splitmix64), independent of numpy's
+global RNG, so the GPU box regenerates bit-identical inputs.
+
+Geometry follows the only in-tree trainer (examples/hough_tree_trainer.rs:149-165): 80x80 patches,
+split rectangles of 0.3 * patch = 24x24 with top-left in [0,56)^2 (src/types.rs:82-91), thresholds
+uniform in [-256, 256) (src/hough/houghforest.rs:230-234), sigma 8, 20 mean-shift iterations
+(src/hough/prediction.rs:225-233).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .forest import NODE_DTYPE, Forest
+
+_G = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+FRAME_SEED_BASE = 0xD0E70000
+FOREST_SEED_BASE = 0xF0BE5700
+
+
+class SplitMix:
+    """Vectorised splitmix64 stream."""
+
+    def __init__(self, seed: int):
+        self.state = np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+
+    def u64(self, n: int) -> np.ndarray:
+        with np.errstate(over="ignore"):
+            z = self.state + np.arange(1, n + 1, dtype=np.uint64) * _G
+            self.state = np.uint64(self.state + np.uint64(n) * _G)
+            z = (z ^ (z >> np.uint64(30))) * _M1
+            z = (z ^ (z >> np.uint64(27))) * _M2
+            return z ^ (z >> np.uint64(31))
+
+    def uniform(self, n: int) -> np.ndarray:
+        return (self.u64(n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    def randint(self, lo: int, hi: int, n: int) -> np.ndarray:
+        """Integers in [lo, hi] inclusive."""
+        return (self.u64(n) % np.uint64(hi - lo + 1)).astype(np.int64) + lo
+
+    def normal(self, n: int) -> np.ndarray:
+        u1 = 1.0 - self.uniform(n)
+        u2 = self.uniform(n)
+        return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def default_intrinsic(w: int = 640, h: int = 480) -> np.ndarray:
+    """`IntrinsicMatrix::default_kinect_intrinsic` (src/types.rs:418-420), scaled with the frame."""
+    f = 560.0 * w / 640.0
+    return np.array([[f, 0.0, w / 2.0], [0.0, f, h / 2.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+
+
+def head_truth(w: int, h: int, seed: int):
+    """(z0, hx, hy, rotation_deg[3]) of the synthetic subject of `biwi_like(w, h, seed)`."""
+    rng = SplitMix(seed)
+    u = rng.uniform(3)
+    z0 = 700.0 + 500.0 * u[0]
+    hx = w * (0.25 + 0.5 * u[1])
+    hy = h * (0.25 + 0.5 * u[2])
+    rot = np.array([(hx - w / 2.0) / w * 80.0, (hy - h / 2.0) / h * 60.0, (z0 - 950.0) / 250.0 * 20.0])
+    return z0, hx, hy, rot
+
+
+def biwi_like(w: int = 640, h: int = 480, seed: int = FRAME_SEED_BASE) -> np.ndarray:
+    """One Kinect-style uint16 depth frame (mm): zero background, a 95 mm sphere "head" at
+    700-1200 mm, a torso slab below it, +-2 mm integer noise and 2 % zero holes."""
+    z0, hx, hy, _ = head_truth(w, h, seed)
+    rng = SplitMix(seed ^ 0x5EED5EED)
+    fx = 560.0 * w / 640.0
+    R = 95.0
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    dxm = (xx - hx) * z0 / fx
+    dym = (yy - hy) * z0 / fx
+    d2 = dxm * dxm + dym * dym
+    depth = np.zeros((h, w), dtype=np.float64)
+    head = d2 < R * R
+    depth[head] = z0 - np.sqrt(R * R - d2[head])
+    rp = R * fx / z0
+    torso = (yy > hy + 0.9 * rp) & (np.abs(xx - hx) < 1.5 * rp) & ~head
+    depth[torso] = z0 + 50.0
+    fg = depth > 0
+    noise = rng.randint(-2, 2, w * h).reshape(h, w)
+    holes = rng.uniform(w * h).reshape(h, w) < 0.02
+    out = np.where(fg, np.rint(depth) + noise, 0.0)
+    out[holes] = 0.0
+    return np.clip(out, 0, 65535).astype(np.uint16)
+
+
+def biwi_batch(n: int, w: int = 640, h: int = 480, first: int = 0) -> np.ndarray:
+    """Frames `first .. first+n-1` of the canonical stream (seed = FRAME_SEED_BASE + index)."""
+    out = np.empty((n, h, w), dtype=np.uint16)
+    for i in range(n):
+        out[i] = biwi_like(w, h, FRAME_SEED_BASE + first + i)
+    return out
+
+
+def synth_forest(n_trees: int = 10, max_depth: int = 15, seed: int = FOREST_SEED_BASE,
+                 patch: tuple[int, int] = (80, 80), rect_scale: float = 0.3,
+                 full_depth: int = 6, p_split: float = 0.75) -> Forest:
+    """Random forest with the trainer's geometry.
+
+    Structure: nodes shallower than `full_depth` always split, deeper ones split with probability
+    `p_split` until `max_depth` (the reference stops at depth >= max_depth,
+    src/hough/houghforest.rs:306).  Nodes of a tree are numbered breadth-first and stored
+    contiguously, so the top levels of every tree are one dense prefix.
+
+    So that a realistic share of patches passes the mean-probability gate (prob > 0.7,
+    src/hough/prediction.rs:584) the root of every tree tests "patch centre in front of the rows
+    above it" and leaves below its `one` child are positive with p = 0.95, those below `zero` with
+    p = 0.1.  Positive leaves carry 2..24 votes; the per-leaf spread varies so both covariance
+    gates (prediction.rs:600, :643) fire and fail.
+    """
+    pw, ph = patch
+    rw, rh = int(pw * rect_scale), int(ph * rect_scale)
+    rng = SplitMix(seed)
+    roots = np.zeros(n_trees, dtype=np.int32)
+    node_chunks, leaf_side_chunks = [], []
+    node_base = leaf_base = 0
+    for t in range(n_trees):
+        # ---- structure, level by level (slots = child positions still to fill)
+        cz = np.zeros(0, dtype=np.int64); co = np.zeros(0, dtype=np.int64)   # per node (local, BFS order)
+        leaf_side = []
+        slot_parent = np.array([-1]); slot_which = np.array([0]); slot_side = np.array([0])
+        n_nodes = n_leaves = 0
+        root_val = 0
+        for d in range(max_depth + 1):
+            k = slot_parent.size
+            if k == 0:
+                break
+            u = rng.uniform(k)
+            split = np.full(k, d < max_depth) & ((d < full_depth) | (u < p_split))
+            ns = int(split.sum()); nl = k - ns
+            val = np.empty(k, dtype=np.int64)
+            val[split] = node_base + n_nodes + np.arange(ns)
+            val[~split] = ~(leaf_base + n_leaves + np.arange(nl))
+            leaf_side.append(slot_side[~split])
+            if d == 0:
+                root_val = int(val[0])
+            else:  # hook into parents
+                sel = slot_which == 0
+                cz[slot_parent[sel]] = val[sel]
+                co[slot_parent[~sel]] = val[~sel]
+            cz = np.concatenate([cz, np.zeros(ns, dtype=np.int64)])
+            co = np.concatenate([co, np.zeros(ns, dtype=np.int64)])
+            new_ids = n_nodes + np.arange(ns)
+            n_nodes += ns; n_leaves += nl
+            side_new = slot_side[split]
+            slot_parent = np.repeat(new_ids, 2)
+            slot_which = np.tile(np.array([0, 1]), ns)
+            slot_side = np.repeat(side_new, 2) if d > 0 else np.tile(np.array([0, 1]), ns)
+        roots[t] = root_val
+        nodes = np.zeros(n_nodes, dtype=NODE_DTYPE)
+        nodes["child_zero"] = cz.astype(np.int32)
+        nodes["child_one"] = co.astype(np.int32)
+        for key in ("r1", "r2"):
+            x0 = rng.randint(0, pw - rw - 1, n_nodes)
+            y0 = rng.randint(0, ph - rh - 1, n_nodes)
+            nodes[key] = np.stack([x0, y0, x0 + rw, y0 + rh], axis=1).astype(np.uint16)
+        nodes["threshold"] = rng.uniform(n_nodes) * 512.0 - 256.0
+        if n_nodes:
+            cx0, cy0 = (pw - rw) // 2, (ph - rh) // 2
+            nodes["r1"][0] = (cx0, cy0, cx0 + rw, cy0 + rh)
+            tx = int(rng.randint(0, pw - rw - 1, 1)[0])
+            ty = int(rng.randint(0, 7, 1)[0])
+            nodes["r2"][0] = (tx, ty, tx + rw, ty + rh)
+            nodes["threshold"][0] = 50.0 + 100.0 * rng.uniform(1)[0]
+        node_chunks.append(nodes)
+        leaf_side_chunks.append(np.concatenate(leaf_side) if leaf_side else np.zeros(0, dtype=np.int64))
+        node_base += n_nodes; leaf_base += n_leaves
+
+    nodes = np.concatenate(node_chunks) if node_chunks else np.zeros(0, dtype=NODE_DTYPE)
+    side = np.concatenate(leaf_side_chunks)
+    L = side.size
+    positive = rng.uniform(L) < np.where(side == 1, 0.95, 0.1)
+    n_votes = np.where(positive, rng.randint(2, 24, L), 0)
+    m_neg = (rng.uniform(L) * (n_votes // 4 + 1)).astype(np.int64)
+    prob = np.where(positive, n_votes / np.maximum(n_votes + m_neg, 1), 0.0)
+    begin = np.zeros(L + 1, dtype=np.uint32)
+    np.cumsum(n_votes, out=begin[1:])
+    nv = int(begin[-1])
+    leaf_of_vote = np.repeat(np.arange(L), n_votes)
+    mu_off = (rng.uniform(L * 3).reshape(L, 3) * 300.0 - 150.0)
+    sg_off = 10.0 + 50.0 * rng.uniform(L)
+    mu_rot = (rng.uniform(L * 3).reshape(L, 3) * 120.0 - 60.0)
+    sg_rot = 2.0 + 14.0 * rng.uniform(L)
+    offsets = (mu_off[leaf_of_vote] + rng.normal(nv * 3).reshape(nv, 3) * sg_off[leaf_of_vote, None]).astype(np.float32)
+    rotations = mu_rot[leaf_of_vote] + rng.normal(nv * 3).reshape(nv, 3) * sg_rot[leaf_of_vote, None]
+    return Forest(roots, nodes, prob, begin, begin.copy(), offsets, rotations)
+
+
+class ModelParams:
+    """The serialised scalars of `HoughPrediction` (src/hough/prediction.rs:239-256)."""
+
+    def __init__(self, stepwidth=10, subimage_width=80, subimage_height=80, gaussian_sigma=8.0,
+                 meanshift_iterations=20):
+        self.stepwidth = int(stepwidth)
+        self.subimage_width = int(subimage_width)
+        self.subimage_height = int(subimage_height)
+        self.gaussian_sigma = float(gaussian_sigma)
+        self.meanshift_iterations = int(meanshift_iterations)
+
+    def patch_grid(self, w: int, h: int) -> tuple[int, int]:
+        """Sliding-window positions (src/hough/prediction.rs:535-548, 684-686)."""
+        lw = self.subimage_width // 2; rw = self.subimage_width - lw
+        lh = self.subimage_height // 2; rh = self.subimage_height - lh
+        nx = len(range(lw, w - rw, self.stepwidth)) if w >= self.subimage_width else 0
+        ny = len(range(lh, h - rh, self.stepwidth)) if h >= self.subimage_height else 0
+        return nx, ny

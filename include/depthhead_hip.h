@@ -1,0 +1,186 @@
+/*
+ * depthhead_hip.h -- C ABI of libdepthhead_hip.so: the MI355X (gfx950) implementation of
+ * depthhead's Hough-forest head-pose inference path.
+ *
+ * The reference (Entscheider/depthhead, pure Rust) has no FFI or plugin interface; its public
+ * seam for this path is
+ *     HoughPrediction::predict_parameter_parallel(&self, img: Arc<DepthImage>,
+ *         intrinsic: &IntrinsicMatrix, midp_guess: Option<[f32;3]>, rot_guess: Option<[f64;3]>)
+ *         -> PredictionResult                                   (src/hough/prediction.rs:397-409)
+ * and its serial twin predict_parameter (:376-388).  This library sits where
+ * predict_parameter_generic (:421-493) sits, with a FRAME BATCH as the unit of work, so a Rust
+ * `extern "C"` shim can keep the method signature unchanged.
+ *
+ * Plain C: pointers and sizes only.  Every entry point returns an int status (0 = DH_OK,
+ * negative = error) and never throws or aborts across the boundary; dh_last_error() gives the
+ * message of the calling thread's last failure.
+ *
+ * Threading (mirrors `HoughPrediction: !Sync`, prediction.rs:253 / types.rs:405): a dh_forest is
+ * immutable and may be shared; a dh_predictor is NOT thread-safe -- one per host thread / GPU
+ * stream.  Distinct predictors may run concurrently.
+ */
+#ifndef DEPTHHEAD_HIP_H
+#define DEPTHHEAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DH_VERSION 100 /* 0.1.0 */
+
+/* ---- status codes ---- */
+#define DH_OK 0
+#define DH_EINVAL (-1)  /* NULL / out-of-range argument                                    */
+#define DH_EFOREST (-2) /* forest violates an invariant the reference would panic on        */
+#define DH_EHIP (-3)    /* HIP runtime error (message has the hipError string)              */
+#define DH_ENOMEM (-4)  /* host or device allocation failed                                 */
+#define DH_ESIZE (-5)   /* geometry unsupported: frame smaller than the patch, etc.         */
+#define DH_ESTATE (-6)  /* call not valid in this state (e.g. debug tap without a batch)    */
+
+/* ---- compile-time constants of the reference (src/hough/prediction.rs:270-286, :314, :584) ---- */
+#define DH_ZSCALEFACTOR 1
+#define DH_GUESS_GRID_PARTS 20
+#define DH_ROT_GRID_PARTS 120
+#define DH_MAX_VARIANCE_ROT 400.0
+#define DH_MAX_VARIANCE_OFFSET 5200.0f
+#define DH_MEANSHIFT_KERNEL_SIZE 20
+#define DH_PROB_GATE 0.7
+
+/* One split node.  Replaces houghforest.rs:63-68 `NodeParam{r1: Rect, r2: Rect, threshold: f64}`
+ * plus the child links stamm keeps.  r = {x0, y0, x1, y1}: Rect.topleft / Rect.bottomright
+ * (src/types.rs:33-37), relative to the patch.  child >= 0 is a node index, child < 0 is the leaf
+ * ~child.  child_one is taken when avg(r1) - avg(r2) > threshold (Binar::One,
+ * houghforest.rs:185-193), child_zero otherwise. */
+typedef struct dh_node {
+    uint16_t r1[4];
+    uint16_t r2[4];
+    double   threshold;
+    int32_t  child_zero;
+    int32_t  child_one;
+} dh_node; /* 32 bytes */
+
+/* Host-side description of a forest; dh_forest_create copies everything.  Replaces the serde
+ * model `RandomForest<LeafParam, HoughTreeFunctions>` (prediction.rs:33-34) with
+ * `LeafParam{prob: f64, offsets: Vec<Vec3<f32>>, rotations: Vec<Vec3<f64>>}` (houghforest.rs:73-78)
+ * in CSR form. */
+typedef struct dh_forest_desc {
+    uint32_t        n_trees;
+    const int32_t  *roots;      /* [n_trees] node index, or ~leaf for a single-leaf tree */
+    uint32_t        n_nodes;
+    const dh_node  *nodes;      /* [n_nodes] */
+    uint32_t        n_leaves;
+    const double   *leaf_prob;  /* [n_leaves] */
+    const uint32_t *off_begin;  /* [n_leaves + 1] into offsets   */
+    const uint32_t *rot_begin;  /* [n_leaves + 1] into rotations */
+    const float    *offsets;    /* [off_begin[n_leaves] * 3] mm      */
+    const double   *rotations;  /* [rot_begin[n_leaves] * 3] degrees */
+} dh_forest_desc;
+
+/* The serialised scalars of `HoughPrediction` (prediction.rs:239-256). */
+typedef struct dh_params {
+    uint32_t stepwidth;
+    uint32_t subimage_width;
+    uint32_t subimage_height;
+    float    gaussian_sigma;        /* used as the VARIANCE of the kernel, prediction.rs:314 */
+    uint32_t meanshift_iterations;
+} dh_params;
+
+/* `PredictionResult` (prediction.rs:259-267).  bounding_box is always Rect(0,0,0,0) there
+ * (:491) and is not carried.  36 payload bytes; `reserved` fills the natural padding and is 0. */
+typedef struct dh_pose {
+    float    mid_point[3]; /* mm, camera space, integer-valued          */
+    uint32_t reserved;
+    double   rotation[3];  /* radians, multiples of 3.14159/60          */
+} dh_pose; /* 40 bytes */
+
+typedef struct dh_forest dh_forest;       /* opaque, immutable */
+typedef struct dh_predictor dh_predictor; /* opaque, one per thread/stream */
+
+/* Average duration of each kernel over the last batch, when profiling is on. */
+typedef struct dh_timing {
+    float traverse_ms; /* SAT tile build + tree walks + gates + hit records */
+    float vote_ms;     /* coarse 20x20 / 20^3 guess grids                    */
+    float cluster_ms;  /* initial guesses + both mean shifts                 */
+    float total_ms;    /* first kernel start -> last kernel end              */
+    uint32_t n_frames;
+    uint32_t reserved;
+} dh_timing;
+
+const char *dh_last_error(void);
+int dh_version(void);
+
+/* Validate and copy a forest.  Rejected with DH_EFOREST where the reference would panic or read
+ * out of bounds: child/root index out of range, a node reachable twice (cycle / DAG), a rectangle
+ * with x1 < x0 or y1 < y0 (u32 underflow, types.rs:47-52), non-monotone CSR arrays, a leaf with
+ * prob > 0 and no offset (division by zero, prediction.rs:594) or no rotation (unwrap of None,
+ * :600), a rotation whose bin leaves [0,120) after the single wrap (index out of bounds, :636). */
+int dh_forest_create(const dh_forest_desc *desc, dh_forest **out);
+int dh_forest_destroy(dh_forest *f);
+int dh_forest_info(const dh_forest *f, uint32_t *n_trees, uint32_t *n_nodes, uint32_t *n_leaves,
+                   uint32_t *max_depth);
+
+/* Upload the forest to `device`, precompute the per-leaf vote tables on the GPU and build the
+ * mean-shift kernel table (get_or_build_kernel, prediction.rs:310-317).  Rejects (DH_EFOREST) a
+ * split rectangle that leaves the patch and (DH_ESIZE) a patch whose pixel sum can exceed 2^32. */
+int dh_predictor_create(const dh_forest *f, const dh_params *p, int device, dh_predictor **out);
+int dh_predictor_destroy(dh_predictor *p);
+/* HoughPrediction::update_sigma / sigma (prediction.rs:320-331): no-op for val <= 0 or unchanged. */
+int dh_predictor_update_sigma(dh_predictor *p, float val);
+int dh_predictor_sigma(const dh_predictor *p, float *out);
+
+/* predict_parameter_parallel over n frames held in HOST memory (row-major u16, index y*w+x,
+ * types.rs:10).  K: row-major 3x3 intrinsic (types.rs:405).  midp_guess (n*3 f32) / rot_guess
+ * (n*3 f64, radians) are the Option<> arguments: NULL = None for every frame; guess_mask (n bytes,
+ * may be NULL = all present) selects per frame: bit0 = midp_guess is Some, bit1 = rot_guess is
+ * Some.  Synchronous: copies in, runs, copies out. */
+int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                     const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
+                     dh_pose *out);
+
+/* Same with DEVICE pointers (frames, guesses, mask, out all device-resident) on `stream`
+ * (a hipStream_t; NULL = default stream).  Asynchronous: returns after enqueueing; buffers must
+ * stay valid until the stream reaches this point.  Performs no allocation and no host
+ * synchronisation once the workspace for (n, w, h) exists, so it can be captured in a hipGraph
+ * (call dh_predictor_reserve first). */
+int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h,
+                            const float K[9], const float *midp_guess, const double *rot_guess,
+                            const uint8_t *guess_mask, dh_pose *out, void *stream);
+
+/* Allocate the workspace for batches of up to n frames of w x h. */
+int dh_predictor_reserve(dh_predictor *p, int n, int w, int h);
+
+/* Number of sliding-window positions for a frame size (prediction.rs:535-548, 684-686). */
+int dh_patch_grid(const dh_params *p, int w, int h, int *nx, int *ny);
+
+/* ---- profiling ---- */
+int dh_set_profiling(dh_predictor *p, int on); /* HIP events around each kernel, on the launch stream */
+int dh_get_timing(dh_predictor *p, dh_timing *out); /* synchronises the recorded events */
+
+/* ---- parity taps (tests only; each refers to the LAST batch run on this predictor) ----
+ * dh_debug_enable(1) makes the next batch record leaf indices, patch flags and mean-shift traces. */
+int dh_debug_enable(dh_predictor *p, int on);
+/* [n][n_patches][n_trees] leaf index per (patch, tree), -1 for background patches. */
+int dh_debug_leaf_indices(dh_predictor *p, int32_t *out, size_t cap_elems);
+/* [n][n_patches]: bit0 = non-background (prediction.rs:567-571), bit1 = prob gate passed (:584). */
+int dh_debug_patch_flags(dh_predictor *p, uint8_t *out, size_t cap_elems);
+/* Coarse guess grids (prediction.rs:529-533): pos_grid [n][400], rot_grid [n][8000]. */
+int dh_debug_grids(dh_predictor *p, uint32_t *pos_grid, uint32_t *rot_grid);
+/* [n][6]: mean-shift start cells, mid x,y,z then rot x,y,z (prediction.rs:437-460, :750). */
+int dh_debug_guesses(dh_predictor *p, int32_t *out);
+/* Every vote of one frame as (x, y, z, value) records, unaggregated and in no particular order:
+ * which = 0 the position accumulator `mid` (prediction.rs:667), 1 the rotation accumulator `rot`
+ * (:635).  *count receives the number of votes (may exceed cap; then only cap are written). */
+int dh_debug_votes(dh_predictor *p, int frame, int which, int32_t *out, size_t cap_records, size_t *count);
+/* Mean-shift positions: trace [n][iterations+1][3] (entry 0 = start), steps [n] = updates done
+ * (meanshift.rs:336-395). which as above. */
+int dh_debug_meanshift(dh_predictor *p, int which, int32_t *trace, uint32_t *steps);
+/* Per-frame number of (patch, leaf) hit records kept for voting. */
+int dh_debug_hit_counts(dh_predictor *p, uint32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEPTHHEAD_HIP_H */

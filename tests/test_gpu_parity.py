@@ -1,0 +1,262 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, stage by stage.
+
+Bar (BASELINE.json north_star): leaf indices bit-exact; mid_point / rotation within 1e-4 -- both are
+integer-grid values (src/hough/prediction.rs:477-489), so the tests demand exact equality, which
+implies the 1e-4 tolerance.  Integer stages (flags, grids, guesses, accumulators, mean-shift
+positions) are compared bit for bit.
+"""
+import numpy as np
+import pytest
+
+from depthhead_amd import synth
+from depthhead_amd.forest import Forest, NODE_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-4   # north_star tolerance; results are integer-grid so we also assert equality
+
+
+@pytest.fixture(scope="module")
+def hp_mod(hip_lib):
+    from depthhead_amd import prediction
+    return prediction
+
+
+def _check_frames(hp_mod, oracle, forest, model, frames, K, midp=None, rot=None, mask=None, full=True):
+    n, h, w = frames.shape
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.debug_enable(True)
+        poses = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K), midp, rot, mask)
+        leaf = hp.debug_leaf_indices(n, w, h)
+        flags = hp.debug_patch_flags(n, w, h)
+        pos_grid, rot_grid = hp.debug_grids(n)
+        guesses = hp.debug_guesses(n)
+        tr_mid, st_mid = hp.debug_meanshift(n, 0)
+        tr_rot, st_rot = hp.debug_meanshift(n, 1)
+        votes = [(hp.debug_votes(i, 0), hp.debug_votes(i, 1)) for i in range(n)] if full else None
+    it = model.meanshift_iterations
+    for i in range(n):
+        mg = None if midp is None or (mask is not None and not mask[i] & 1) else midp[i]
+        rg = None if rot is None or (mask is not None and not mask[i] & 2) else rot[i]
+        ref = oracle.predict(forest, model, frames[i], K, mg, rg)
+        assert np.array_equal(leaf[i], ref.leaf_idx), f"frame {i}: leaf indices"
+        assert np.array_equal(flags[i], ref.patch_flags), f"frame {i}: patch flags"
+        assert np.array_equal(pos_grid[i], ref.pos_grid), f"frame {i}: 20x20 guess grid"
+        assert np.array_equal(rot_grid[i], ref.rot_grid), f"frame {i}: 20^3 guess grid"
+        assert np.array_equal(guesses[i, :3], ref.guess_mid), f"frame {i}: mid guess {guesses[i]} vs {ref.guess_mid}"
+        assert np.array_equal(guesses[i, 3:], ref.guess_rot), f"frame {i}: rot guess {guesses[i]} vs {ref.guess_rot}"
+        if full:
+            assert np.array_equal(hp_mod.aggregate_votes(votes[i][0]), ref.mid_cells), f"frame {i}: mid accumulator"
+            assert np.array_equal(hp_mod.aggregate_votes(votes[i][1]), ref.rot_cells), f"frame {i}: rot accumulator"
+        for name, tr, st, rtr in (("mid", tr_mid, st_mid, ref.ms_trace_mid), ("rot", tr_rot, st_rot, ref.ms_trace_rot)):
+            k = rtr.shape[0]   # oracle steps + 1
+            # the kernel stops at a fixed point and reports the remaining (identical) steps as done
+            assert st[i] + 1 >= k or st[i] == it, f"frame {i}: {name} steps {st[i]} vs {k - 1}"
+            assert np.array_equal(tr[i, :k], rtr), f"frame {i}: {name} mean-shift trace"
+        assert np.array_equal(poses["mid_point"][i], ref.mid_point), f"frame {i}: {poses['mid_point'][i]} vs {ref.mid_point}"
+        assert np.array_equal(poses["rotation"][i], ref.rotation), f"frame {i}: {poses['rotation'][i]} vs {ref.rotation}"
+        assert np.max(np.abs(poses["mid_point"][i] - ref.mid_point)) <= POSE_TOL
+        assert np.max(np.abs(poses["rotation"][i] - ref.rotation)) <= POSE_TOL
+    return poses
+
+
+@pytest.mark.parametrize("w,h,step,trees,depth", [
+    (160, 120, 4, 5, 8),
+    (200, 152, 3, 10, 12),
+    (320, 240, 1, 3, 6),     # BASELINE config 5 geometry, small forest
+    (320, 240, 7, 10, 15),
+])
+def test_stagewise_small(hp_mod, oracle, w, h, step, trees, depth):
+    forest = synth.synth_forest(trees, depth, synth.FOREST_SEED_BASE + 100 + step)
+    model = synth.ModelParams(stepwidth=step)
+    frames = synth.biwi_batch(3, w, h, first=10)
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h))
+
+
+def test_config1_single_frame_stride10(hp_mod, oracle):
+    """BASELINE config 1: one 640x480 frame, 10-tree forest, trainer stride 10."""
+    forest = synth.synth_forest(10, 15, synth.FOREST_SEED_BASE + 1)
+    model = synth.ModelParams(stepwidth=10)
+    frames = synth.biwi_batch(1, 640, 480)
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic())
+
+
+def test_config2_stride4_batch(hp_mod, oracle):
+    """BASELINE config 2 geometry (640x480, 10 trees, stride 4) on a 6-frame slice."""
+    forest = synth.synth_forest(10, 15, synth.FOREST_SEED_BASE + 2)
+    model = synth.ModelParams(stepwidth=4)
+    frames = synth.biwi_batch(6, 640, 480, first=3)
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic())
+
+
+def test_config3_deep_forest_stride2(hp_mod, oracle):
+    """BASELINE config 3 geometry (stride 2, depth 20) with 12 trees to keep the oracle quick."""
+    forest = synth.synth_forest(12, 20, synth.FOREST_SEED_BASE + 3)
+    model = synth.ModelParams(stepwidth=2)
+    frames = synth.biwi_batch(2, 640, 480, first=40)
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(), full=False)
+
+
+def test_guess_overrides(hp_mod, oracle):
+    """midp_guess / rot_guess Options (prediction.rs:437-460), per frame via guess_mask."""
+    forest = synth.synth_forest(8, 10, synth.FOREST_SEED_BASE + 4)
+    model = synth.ModelParams(stepwidth=5)
+    w, h, n = 320, 240, 4
+    frames = synth.biwi_batch(n, w, h, first=20)
+    K = synth.default_intrinsic(w, h)
+    base = _check_frames(hp_mod, oracle, forest, model, frames, K)
+    midp = (base["mid_point"] + np.array([3.7, -2.2, 5.9], dtype=np.float32)).astype(np.float32)
+    rot = base["rotation"] + 0.04
+    _check_frames(hp_mod, oracle, forest, model, frames, K, midp, rot)
+    mask = np.array([0, 1, 2, 3], dtype=np.uint8)
+    _check_frames(hp_mod, oracle, forest, model, frames, K, midp, rot, mask)
+    wild_m = np.array([[1e20, -1e20, np.nan]] * n, dtype=np.float32)   # saturating / NaN casts
+    wild_r = np.array([[1e300, -7.0, np.nan]] * n, dtype=np.float64)
+    _check_frames(hp_mod, oracle, forest, model, frames, K, wild_m, wild_r)
+
+
+def test_edge_frames(hp_mod, oracle):
+    """All-background frame, frame exactly one patch wide (zero window positions), saturated frame."""
+    forest = synth.synth_forest(4, 8, synth.FOREST_SEED_BASE + 5)
+    model = synth.ModelParams(stepwidth=4)
+    K = synth.default_intrinsic(160, 120)
+    zero = np.zeros((2, 120, 160), dtype=np.uint16)
+    zero[1, 60, 80] = 1   # a single non-zero pixel
+    _check_frames(hp_mod, oracle, forest, model, zero, K)
+    full = np.full((1, 120, 160), 65535, dtype=np.uint16)
+    _check_frames(hp_mod, oracle, forest, model, full, K)
+    tiny = synth.biwi_batch(1, 160, 120)[:, :80, :80].copy()   # w == sw: the loops run zero times
+    _check_frames(hp_mod, oracle, forest, model, tiny, synth.default_intrinsic(80, 80))
+    one = synth.biwi_batch(1, 160, 120)[:, :81, :83].copy()     # exactly one row of three positions... (1 x 3)
+    _check_frames(hp_mod, oracle, forest, synth.ModelParams(stepwidth=1), one, synth.default_intrinsic(83, 81))
+
+
+def _hand_forest():
+    """Two trees built by hand: a single-leaf tree, zero-area rectangles, a one-vote leaf (its
+    covariance is 0/0 = NaN so it never votes, meancov_estimation.rs:376), a leaf whose rotation
+    wraps at +-180 degrees, equal-threshold ties."""
+    nodes = np.zeros(3, dtype=NODE_DTYPE)
+    nodes[0] = ((10, 10, 34, 34), (40, 40, 64, 64), 0.0, 1, ~0)          # avg1-avg2 > 0 ? leaf0 : node1
+    nodes[1] = ((0, 0, 0, 0), (5, 5, 5, 30), -1.0, ~1, 2)                # two empty rects: 0-0 > -1 -> node2
+    nodes[2] = ((0, 0, 80, 80), (0, 0, 1, 1), 100.0, ~2, ~3)
+    roots = np.array([0, ~4], dtype=np.int32)                            # tree 1 is a single leaf
+    prob = np.array([0.9, 0.5, 1.0, 0.8, 1.0])
+    noff = [3, 1, 4, 2, 3]
+    off_begin = np.concatenate([[0], np.cumsum(noff)]).astype(np.uint32)
+    offsets = np.array([[10, 5, -20], [12, 6, -22], [9, 4, -19],
+                        [0, 0, 0],
+                        [-30, 10, 15], [-31, 11, 16], [-29, 9, 14], [-30.5, 10.5, 15.5],
+                        [1e6, 0, 0], [-1e6, 0, 0],                        # huge spread: offset gate fails
+                        [0.5, 0.5, 2000.0], [0.25, 0.75, 1999.0], [0.1, 0.2, 2001.0]], dtype=np.float32)  # np.z < 0 skips
+    rotations = np.array([[181.0, -185.0, 10], [178.0, -178.0, 11], [179.9, -179.9, 9],   # 181 -> bin 120 -> 0; -185 -> -1 -> 119
+                          [5, 5, 5],
+                          [20, -30, 40], [21, -31, 41], [19, -29, 39], [20.5, -30.5, 40.5],
+                          [0, 0, 0], [90, 90, 90],                        # trace > 400: rotation gate fails
+                          [-2.9, 2.9, 0.0], [-3.1, 3.1, -0.0], [-1.0, 1.0, 0.5]], dtype=np.float64)
+    return Forest(roots, nodes, prob, off_begin, off_begin.copy(), offsets, rotations)
+
+
+def test_hand_built_forest(hp_mod, oracle):
+    forest = _hand_forest()
+    model = synth.ModelParams(stepwidth=6, meanshift_iterations=7)
+    frames = synth.biwi_batch(3, 200, 160, first=5)
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(200, 160))
+
+
+def test_non_square_odd_patch_and_dense_intrinsic(hp_mod, oracle):
+    """Odd, non-square patch (left/right halves differ, prediction.rs:535-538) and the dense
+    intrinsic of the reference's own test (types.rs:478)."""
+    forest = synth.synth_forest(5, 9, synth.FOREST_SEED_BASE + 6, patch=(61, 47))
+    model = synth.ModelParams(stepwidth=3, subimage_width=61, subimage_height=47, gaussian_sigma=3.5, meanshift_iterations=5)
+    frames = synth.biwi_batch(2, 180, 140, first=7)
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(180, 140))
+    K = np.array([[22.0, 11.4, 12.11], [2.1, 4.1, 2.11], [1.3, 3.1, 19.0]], dtype=np.float32)
+    _check_frames(hp_mod, oracle, forest, model, frames, K)
+
+
+def test_update_sigma(hp_mod, oracle):
+    forest = synth.synth_forest(6, 10, synth.FOREST_SEED_BASE + 7)
+    model = synth.ModelParams(stepwidth=4)
+    frames = synth.biwi_batch(2, 320, 240, first=30)
+    K = synth.default_intrinsic(320, 240)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        a = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        hp.update_sigma(-1.0)            # ignored (prediction.rs:321)
+        assert hp.sigma() == 8.0
+        hp.update_sigma(2.5)
+        assert hp.sigma() == 2.5
+        b = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+    m2 = synth.ModelParams(stepwidth=4, gaussian_sigma=2.5)
+    for i in range(2):
+        ra = oracle.predict(forest, model, frames[i], K, taps=False)
+        rb = oracle.predict(forest, m2, frames[i], K, taps=False)
+        assert np.array_equal(a["mid_point"][i], ra.mid_point) and np.array_equal(a["rotation"][i], ra.rotation)
+        assert np.array_equal(b["mid_point"][i], rb.mid_point) and np.array_equal(b["rotation"][i], rb.rotation)
+
+
+def test_single_frame_api_matches_reference_signature(hp_mod, oracle):
+    """predict_parameter_parallel(img, intrinsic, midp_guess, rot_guess) -> PredictionResult."""
+    forest = synth.synth_forest(10, 15, synth.FOREST_SEED_BASE + 1)
+    model = synth.ModelParams(stepwidth=10)
+    img = synth.biwi_like(640, 480, synth.FRAME_SEED_BASE + 77)
+    intr = hp_mod.IntrinsicMatrix.default_kinect_intrinsic()
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        r0 = hp.predict_parameter_parallel(img, intr, None, None)
+        r1 = hp.predict_parameter(img, intr, None, None)
+        r2 = hp.predict_parameter_parallel(img, intr, r0.mid_point, r0.rotation)   # live_prediction.rs:81-86
+    ref0 = oracle.predict(forest, model, img, intr.mat, taps=False)
+    ref2 = oracle.predict(forest, model, img, intr.mat, ref0.mid_point, ref0.rotation, taps=False)
+    assert np.array_equal(r0.mid_point, ref0.mid_point) and np.array_equal(r0.rotation, ref0.rotation)
+    assert np.array_equal(r1.mid_point, r0.mid_point) and np.array_equal(r1.rotation, r0.rotation)
+    assert np.array_equal(r2.mid_point, ref2.mid_point) and np.array_equal(r2.rotation, ref2.rotation)
+    assert r0.bounding_box == (0, 0, 0, 0)
+
+
+def test_full_size_batch_properties(hp_mod, oracle):
+    """BASELINE config 2 at full size (256 frames): size-independent properties -- results do not
+    depend on batch composition or position, runs are deterministic, and a sample of frames matches
+    the oracle."""
+    forest = synth.synth_forest(10, 15, synth.FOREST_SEED_BASE + 2)
+    model = synth.ModelParams(stepwidth=4)
+    base = synth.biwi_batch(32, 640, 480)
+    frames = np.concatenate([base] * 8)                   # 256 frames, every frame appears 8 times
+    perm = np.random.RandomState(1).permutation(256)
+    K = synth.default_intrinsic()
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        a = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        b = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        c = hp.predict_batch(frames[perm], hp_mod.IntrinsicMatrix(K))
+        d = hp.predict_batch(frames[:5], hp_mod.IntrinsicMatrix(K))
+    assert a.tobytes() == b.tobytes()                      # deterministic
+    assert np.array_equal(c["mid_point"], a["mid_point"][perm]) and np.array_equal(c["rotation"], a["rotation"][perm])
+    assert np.array_equal(d["mid_point"], a["mid_point"][:5])
+    for r in range(1, 8):                                  # replicas agree
+        assert np.array_equal(a["mid_point"][r * 32:(r + 1) * 32], a["mid_point"][:32])
+        assert np.array_equal(a["rotation"][r * 32:(r + 1) * 32], a["rotation"][:32])
+    ref = oracle.predict_batch(forest, model, base[:16], K)
+    assert np.array_equal(a["mid_point"][:16], ref["mid_point"]) and np.array_equal(a["rotation"][:16], ref["rotation"])
+
+
+def test_device_resident_api_with_torch_stream(hp_mod, oracle):
+    """dh_predict_batch_device on torch-owned device memory and a non-default torch stream."""
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    forest = synth.synth_forest(6, 10, synth.FOREST_SEED_BASE + 8)
+    model = synth.ModelParams(stepwidth=4)
+    w, h, n = 320, 240, 5
+    frames = synth.biwi_batch(n, w, h, first=60)
+    K = synth.default_intrinsic(w, h)
+    dev = torch.device("cuda:0")
+    from depthhead_amd._lib import POSE_DTYPE
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.reserve(n, w, h)
+        fr = torch.from_numpy(frames.view(np.int16)).to(dev)
+        out = torch.zeros(n * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        st = torch.cuda.Stream(device=dev)
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            hp.predict_batch_device(fr.data_ptr(), n, w, h, hp_mod.IntrinsicMatrix(K), out.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        poses = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)
+    ref = oracle.predict_batch(forest, model, frames, K)
+    assert np.array_equal(poses["mid_point"], ref["mid_point"]) and np.array_equal(poses["rotation"], ref["rotation"])
