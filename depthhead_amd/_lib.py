@@ -61,6 +61,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if os.environ.get("DH_NO_TORCH_PRELOAD") != "1":
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  Two HIP runtimes in one process do
+        # not both see the GPU, so when torch is installed it is imported FIRST: the loader then
+        # resolves this library's libamdhip64.so.7 to the copy torch already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the depthhead_amd product path has no CPU fallback)")

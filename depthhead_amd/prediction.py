@@ -50,7 +50,9 @@ class HoughPrediction:
 
     def __init__(self, forest: Forest, params: ModelParams | None = None, device: int = 0):
         self._lib = _lib.load()
-        self.params = params or ModelParams()
+        src = params or ModelParams()   # private copy: update_sigma must not alias the caller's object
+        self.params = ModelParams(src.stepwidth, src.subimage_width, src.subimage_height, src.gaussian_sigma,
+                                  src.meanshift_iterations)
         self.forest = forest
         self.device = device
         self._fh = C.c_void_p()
