@@ -260,3 +260,38 @@ def test_device_resident_api_with_torch_stream(hp_mod, oracle):
         poses = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)
     ref = oracle.predict_batch(forest, model, frames, K)
     assert np.array_equal(poses["mid_point"], ref["mid_point"]) and np.array_equal(poses["rotation"], ref["rotation"])
+
+
+def test_golden_fixtures_without_oracle(hp_mod):
+    """HIP path against the committed fixtures (tests/golden/*.npz) -- no oracle involved."""
+    import golden_util
+    for name in golden_util.names():
+        forest, model, frames, K, exp = golden_util.load(name)
+        n, h, w = frames.shape
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            hp.debug_enable(True)
+            poses = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+            leaf, flags = hp.debug_leaf_indices(n, w, h), hp.debug_patch_flags(n, w, h)
+            pos_grid, rot_grid = hp.debug_grids(n)
+            guesses = hp.debug_guesses(n)
+            votes = [(hp.debug_votes(i, 0), hp.debug_votes(i, 1)) for i in range(n)]
+            tr_mid, _ = hp.debug_meanshift(n, 0)
+            tr_rot, _ = hp.debug_meanshift(n, 1)
+        for i, e in enumerate(exp):
+            assert np.array_equal(leaf[i], e["leaf_idx"]) and np.array_equal(flags[i], e["patch_flags"]), (name, i)
+            assert np.array_equal(pos_grid[i], e["pos_grid"]) and np.array_equal(rot_grid[i], e["rot_grid"]), (name, i)
+            assert np.array_equal(guesses[i], e["guess"]), (name, i)
+            assert np.array_equal(hp_mod.aggregate_votes(votes[i][0]), e["mid_cells"]), (name, i)
+            assert np.array_equal(hp_mod.aggregate_votes(votes[i][1]), e["rot_cells"]), (name, i)
+            assert np.array_equal(tr_mid[i, :len(e["ms_trace_mid"])], e["ms_trace_mid"]), (name, i)
+            assert np.array_equal(tr_rot[i, :len(e["ms_trace_rot"])], e["ms_trace_rot"]), (name, i)
+            assert np.array_equal(poses["mid_point"][i], e["mid_point"]) and np.array_equal(poses["rotation"][i], e["rotation"]), (name, i)
+
+
+def test_hand_verified_case(hp_mod):
+    """The paper-checked case of tests/test_hand_case.py through the HIP path."""
+    import test_hand_case as hc
+    forest, model, img, K = hc.hand_case()
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        r = hp.predict_parameter_parallel(img, hp_mod.IntrinsicMatrix(K))
+    hc.check(r.mid_point, r.rotation)
