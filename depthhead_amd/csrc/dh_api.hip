@@ -123,6 +123,9 @@ extern "C" int dh_forest_create(const dh_forest_desc *d, dh_forest **out) {
             }
         }
     }
+    for (uint32_t L = 0; L < NL; ++L)
+        if (f->off_begin[L + 1] - f->off_begin[L] >= (1u << 24) || f->rot_begin[L + 1] - f->rot_begin[L] >= (1u << 24))
+            return bad(DH_EFOREST, "leaf %ld: more than 2^24 votes", L);
     // ---- leaves that can vote
     for (uint32_t L = 0; L < NL; ++L) {
         if (!(f->leaf_prob[L] > 0.0)) continue;
@@ -194,6 +197,8 @@ struct dh_predictor {
     uint16_t *ws_frames = nullptr;   // host-API staging only
     size_t ws_frames_bytes = 0;
     HitRec *hits = nullptr;
+    HitBox *hit_box = nullptr;
+    HitRot *hit_rot = nullptr;
     uint32_t hits_cap = 0;
     uint32_t *counters = nullptr;    // [n] hit_count | [n][400] pos_grid | [n][8000] rot_grid (one memset)
     dh_pose *ws_poses = nullptr;
@@ -265,11 +270,11 @@ static int build_kernel_table(dh_predictor *p) {
 }
 
 static void free_workspace(dh_predictor *p) {
-    void *ptrs[] = {p->ws_frames, p->hits, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
+    void *ptrs[] = {p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
                     p->dbg_flags, p->dbg_guess, p->dbg_trace, p->dbg_steps, p->dbg_votes, p->dbg_vcount};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    p->ws_frames = nullptr; p->hits = nullptr; p->counters = nullptr; p->ws_poses = nullptr; p->ws_midp = nullptr;
+    p->ws_frames = nullptr; p->hits = nullptr; p->hit_box = nullptr; p->hit_rot = nullptr; p->counters = nullptr; p->ws_poses = nullptr; p->ws_midp = nullptr;
     p->ws_rot = nullptr; p->ws_mask = nullptr; p->dbg_leaf = nullptr; p->dbg_flags = nullptr; p->dbg_guess = nullptr;
     p->dbg_trace = nullptr; p->dbg_steps = nullptr; p->dbg_votes = nullptr; p->dbg_vcount = nullptr;
     p->ws_frames_bytes = 0; p->dbg_votes_cap = 0; p->cap_frames = 0; p->hits_cap = 0; p->dbg_valid = false;
@@ -369,7 +374,7 @@ extern "C" int dh_predictor_sigma(const dh_predictor *p, float *out) {
 // (SAT footprint + leaf ids), at most 1024 (one thread per position in the gate phase).
 static int choose_tile(const dh_predictor *p, Geom &g) {
     const int step = (int)p->params.stepwidth, sw = (int)p->params.subimage_width, sh = (int)p->params.subimage_height;
-    size_t budget = 100 * 1024;
+    size_t budget = 79 * 1024;   // two 1024-thread workgroups per CU (160 KB LDS)
     if (const char *e = getenv("DH_LDS_BUDGET_KB")) budget = (size_t)atoi(e) * 1024;
     budget = std::min<size_t>(budget, 158 * 1024);
     int fx = 0, fy = 0;
@@ -416,6 +421,8 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     p->hits_cap = (uint32_t)hits_cap;
 #define STEP(x) if (rc == DH_OK) rc = (x)
     STEP(dev_alloc(p, &p->hits, (size_t)cap * hits_cap));
+    STEP(dev_alloc(p, &p->hit_box, (size_t)cap * hits_cap));
+    STEP(dev_alloc(p, &p->hit_rot, (size_t)cap * hits_cap));
     STEP(dev_alloc(p, &p->counters, (size_t)cap * (1 + DH_POSGRID + DH_GRID3)));
     STEP(dev_alloc(p, &p->ws_poses, cap));
     STEP(dev_alloc(p, &p->ws_midp, (size_t)cap * 3));
@@ -470,7 +477,7 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
         ta.ss_max = g.ss_max;
         memcpy(ta.kinv, kinv, sizeof kinv);
         ta.f = p->dev;
-        ta.hits = p->hits; ta.hit_count = hit_count; ta.hits_cap = p->hits_cap;
+        ta.hits = p->hits; ta.hit_box = p->hit_box; ta.hit_rot = p->hit_rot; ta.hit_count = hit_count; ta.hits_cap = p->hits_cap;
         ta.dbg_leaf = p->debug ? p->dbg_leaf : nullptr;
         ta.dbg_flags = p->debug ? p->dbg_flags : nullptr;
         HIP_TRY(dh_launch_traverse(ta, g.lds, s));
@@ -480,7 +487,7 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
         VoteArgs va{};
         va.n_frames = N; va.w = w; va.h = h;
         memcpy(va.k, K, sizeof va.k);
-        va.f = p->dev; va.hits = p->hits; va.hit_count = hit_count; va.hits_cap = p->hits_cap;
+        va.f = p->dev; va.hits = p->hits; va.hit_box = p->hit_box; va.hit_rot = p->hit_rot; va.hit_count = hit_count; va.hits_cap = p->hits_cap;
         va.pos_grid = pos_grid; va.rot_grid = rot_grid;
         HIP_TRY(dh_launch_vote(va, s));
     }
@@ -489,7 +496,7 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
         ClusterArgs ca{};
         ca.frames = frames; ca.n_frames = N; ca.w = w; ca.h = h;
         memcpy(ca.kinv, kinv, sizeof kinv);
-        ca.f = p->dev; ca.hits = p->hits; ca.hit_count = hit_count; ca.hits_cap = p->hits_cap;
+        ca.f = p->dev; ca.hits = p->hits; ca.hit_box = p->hit_box; ca.hit_rot = p->hit_rot; ca.hit_count = hit_count; ca.hits_cap = p->hits_cap;
         ca.pos_grid = pos_grid; ca.rot_grid = rot_grid; ca.kern_ord = p->kern_ord;
         ca.iterations = p->params.meanshift_iterations;
         ca.midp_guess = midp_guess; ca.rot_guess = rot_guess; ca.guess_mask = guess_mask;
@@ -639,7 +646,7 @@ extern "C" int dh_debug_votes(dh_predictor *p, int frame, int which, int32_t *ou
     }
     HIP_TRY(hipMemset(p->dbg_vcount, 0, 4));
     VotesDumpArgs a{};
-    a.frame = frame; a.which = which; a.f = p->dev; a.hits = p->hits; a.hit_count = p->counters; a.hits_cap = p->hits_cap;
+    a.frame = frame; a.which = which; a.f = p->dev; a.hits = p->hits; a.hit_box = p->hit_box; a.hit_rot = p->hit_rot; a.hit_count = p->counters; a.hits_cap = p->hits_cap;
     a.out = p->dbg_votes; a.cap = (uint32_t)cap; a.count = p->dbg_vcount;
     HIP_TRY(dh_launch_votes_dump(a, nullptr));
     HIP_TRY(hipDeviceSynchronize());

@@ -34,15 +34,32 @@ struct DevForest {
     uint16_t *rot_rough;   // per rotation vote: index into the 20^3 grid (:630-636)
     float    *off_min;     // per leaf, 3 floats: component-wise min of its offsets (-inf if non-finite)
     float    *off_max;     // per leaf, 3 floats                                     (+inf if non-finite)
-    uint32_t *rbin_box;    // per leaf: min r1|r2<<8|r3<<16 in low 24 bits... see k_leaf_prepare
-    uint32_t *rbin_box_hi; // per leaf: max bins, same packing
+    uint32_t *rbin_box;    // per leaf: component-wise minimum of its rotation bins, r1 | r2<<8 | r3<<16
+    uint32_t *rbin_box_hi; // per leaf: component-wise maximum, same packing
 };
 
-// One (gated patch, leaf) pair kept for voting: the patch centre in camera space
-// (prediction.rs:554) and the leaf it reached.
+// One (gated patch, voting leaf) pair = three self-contained 16/32-byte records, so that neither the
+// vote kernels nor the mean shift chase leaf tables: after one coalesced record read the only
+// dependent access left is the vote array itself.
 struct __attribute__((aligned(16))) HitRec {
-    float    p3[3];
-    uint32_t leaf;
+    float    p3[3];    // patch centre in camera space (prediction.rs:554)
+    uint32_t ob;       // index of the leaf's first offset vote
+};
+// Cell bounding box of the hit's position votes: cell_k = trunc(p3_k - o_k) is monotone in o_k, so
+// every vote of the leaf lands in [lo_k, hi_k] = [trunc(p3_k - omax_k), trunc(p3_k - omin_k)].
+struct __attribute__((aligned(16))) HitBox {
+    int32_t  lo[3];
+    int32_t  hi0;
+    int32_t  hi1, hi2;
+    uint32_t v;        // valtoadd of the leaf (prediction.rs:594-595)
+    uint32_t fc;       // LF_* flags | n_offsets << 8
+};
+// Rotation votes do not depend on the patch: bounding box of the leaf's rotation bins.
+struct __attribute__((aligned(16))) HitRot {
+    uint32_t lo;       // r1 | r2<<8 | r3<<16 minima; 0xFFFFFFFF when the leaf casts no rotation vote
+    uint32_t hi;
+    uint32_t rb;       // index of the leaf's first rotation vote
+    uint32_t n_rot;
 };
 
 struct TraverseArgs {
@@ -56,6 +73,8 @@ struct TraverseArgs {
     float kinv[9];
     DevForest f;
     HitRec   *hits;
+    HitBox   *hit_box;
+    HitRot   *hit_rot;
     uint32_t *hit_count;    // [n_frames]
     uint32_t  hits_cap;     // records per frame
     int32_t  *dbg_leaf;     // nullable [n][npatch][T]
@@ -67,6 +86,8 @@ struct VoteArgs {
     float k[9];
     DevForest f;
     const HitRec   *hits;
+    const HitBox   *hit_box;
+    const HitRot   *hit_rot;
     const uint32_t *hit_count;
     uint32_t  hits_cap;
     uint32_t *pos_grid;     // [n][400]
@@ -79,6 +100,8 @@ struct ClusterArgs {
     float kinv[9];
     DevForest f;
     const HitRec   *hits;
+    const HitBox   *hit_box;
+    const HitRot   *hit_rot;
     const uint32_t *hit_count;
     uint32_t  hits_cap;
     const uint32_t *pos_grid;
@@ -98,6 +121,8 @@ struct VotesDumpArgs {
     int frame, which;
     DevForest f;
     const HitRec   *hits;
+    const HitBox   *hit_box;
+    const HitRot   *hit_rot;
     const uint32_t *hit_count;
     uint32_t  hits_cap;
     int32_t  *out;          // cap*4

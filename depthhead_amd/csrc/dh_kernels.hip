@@ -178,14 +178,15 @@ hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s) {
 // mean costs 4 LDS reads instead of the reference's O(area) pixel loop (types.rs:317-339).
 #define TRAV_THREADS 1024
 #define TRAV_WAVES (TRAV_THREADS / WAVE)
+#define ROWS_IN_FLIGHT 4
 
 size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees) {
     size_t fw = (size_t)(px - 1) * step + sw, fh = (size_t)(py - 1) * step + sh;
     size_t npt = (size_t)px * py;
-    return ((fw + 1) * (fh + 1) + npt * n_trees + npt * 3 + npt + 16) * 4;
+    return ((fw + 1) * (fh + 1) + npt * n_trees + npt * 3 + npt + 16) * 4;   // keep in step with the carve-up in k_traverse
 }
 
-__global__ void __launch_bounds__(TRAV_THREADS) k_traverse(TraverseArgs a) {
+__global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int T = (int)a.f.n_trees;
@@ -212,42 +213,116 @@ __global__ void __launch_bounds__(TRAV_THREADS) k_traverse(TraverseArgs a) {
 
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
 
-    // ---- phase 1a: row prefix sums, one wave per row, 4 pixels per lane
-    if (tid < 4) misc[tid] = 0;
+    // ---- phase 1a: row prefix sums.  A wave owns rows wave, wave+16, ...; it first issues the
+    // global loads of ROWS_IN_FLIGHT rows (4 pixels per lane, one 8-byte load when aligned) and only
+    // then scans them, so a tile pays two or three global-memory round trips instead of one per row.
+    if (tid < 8) misc[tid] = 0;
     for (int i = tid; i < ss; i += TRAV_THREADS) sat[i] = 0;          // row 0
-    for (int r = wave; r < fh; r += TRAV_WAVES) {
-        const uint16_t *row = img + (size_t)(fy0 + r) * a.w + fx0;
-        uint32_t *dst = sat + (r + 1) * ss;
-        if (lane == 0) dst[0] = 0;                                     // column 0
-        uint32_t carry = 0;
-        for (int x0 = 0; x0 < fw; x0 += WAVE * 4) {
-            int x = x0 + lane * 4;
-            uint32_t p0 = x + 0 < fw ? row[x + 0] : 0u, p1 = x + 1 < fw ? row[x + 1] : 0u,
-                     p2 = x + 2 < fw ? row[x + 2] : 0u, p3 = x + 3 < fw ? row[x + 3] : 0u;
-            uint32_t s0 = p0, s1 = s0 + p1, s2 = s1 + p2, s3 = s2 + p3;
-            uint32_t incl = s3;                                        // wave inclusive scan of lane totals
+    const bool al8 = ((a.w & 3) == 0) && ((fx0 & 3) == 0) && ((((size_t)img) & 7) == 0);
+    const int nchunk = (fw + WAVE * 4 - 1) / (WAVE * 4);
+    uint32_t any_px = 0;
+    for (int r0 = wave; r0 < fh; r0 += TRAV_WAVES * ROWS_IN_FLIGHT) {
+        uint32_t carry[ROWS_IN_FLIGHT];
 #pragma unroll
-            for (int d = 1; d < WAVE; d <<= 1) {
-                uint32_t o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
+        for (int g = 0; g < ROWS_IN_FLIGHT; ++g) carry[g] = 0;
+        for (int c = 0; c < nchunk; ++c) {
+            const int x = c * WAVE * 4 + lane * 4;
+            uint32_t p[ROWS_IN_FLIGHT][4];
+#pragma unroll
+            for (int g = 0; g < ROWS_IN_FLIGHT; ++g) {
+                const int r = r0 + g * TRAV_WAVES;
+                p[g][0] = p[g][1] = p[g][2] = p[g][3] = 0;
+                if (r < fh) {
+                    const uint16_t *row = img + (size_t)(fy0 + r) * a.w + fx0;
+                    if (al8 && x + 3 < fw) {
+                        uint2 q = *(const uint2 *)(row + x);
+                        p[g][0] = q.x & 0xffffu; p[g][1] = q.x >> 16; p[g][2] = q.y & 0xffffu; p[g][3] = q.y >> 16;
+                    } else {
+                        if (x + 0 < fw) p[g][0] = row[x + 0];
+                        if (x + 1 < fw) p[g][1] = row[x + 1];
+                        if (x + 2 < fw) p[g][2] = row[x + 2];
+                        if (x + 3 < fw) p[g][3] = row[x + 3];
+                    }
+                }
             }
-            uint32_t base = carry + incl - s3;
-            if (x + 0 < fw) dst[x + 1] = base + s0;
-            if (x + 1 < fw) dst[x + 2] = base + s1;
-            if (x + 2 < fw) dst[x + 3] = base + s2;
-            if (x + 3 < fw) dst[x + 4] = base + s3;
-            carry += __shfl(incl, WAVE - 1);
+#pragma unroll
+            for (int g = 0; g < ROWS_IN_FLIGHT; ++g) {
+                const int r = r0 + g * TRAV_WAVES;
+                if (r >= fh) continue;          // wave-uniform
+                uint32_t *dst = sat + (r + 1) * ss;
+                if (c == 0 && lane == 0) dst[0] = 0;                   // column 0
+                uint32_t s0 = p[g][0], s1 = s0 + p[g][1], s2 = s1 + p[g][2], s3 = s2 + p[g][3];
+                any_px |= s3;
+                uint32_t incl = s3;                                    // wave inclusive scan of lane totals
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) {
+                    uint32_t o = __shfl_up(incl, d);
+                    if (lane >= d) incl += o;
+                }
+                uint32_t base = carry[g] + incl - s3;
+                if (x + 0 < fw) dst[x + 1] = base + s0;
+                if (x + 1 < fw) dst[x + 2] = base + s1;
+                if (x + 2 < fw) dst[x + 3] = base + s2;
+                if (x + 3 < fw) dst[x + 4] = base + s3;
+                carry[g] += __shfl(incl, WAVE - 1);
+            }
         }
     }
+    if (__ballot(any_px != 0) != 0ull && lane == 0) misc[4] = 1;
     __syncthreads();
-    // ---- phase 1b: column prefix sums, one thread per column
-    for (int x = 1 + tid; x <= fw; x += TRAV_THREADS) {
-        uint32_t run = 0;
-        uint32_t *col = sat + x;
-#pragma unroll 8
-        for (int y = 1; y <= fh; ++y) {
-            run += col[y * ss];
-            col[y * ss] = run;
+    if (misc[4] == 0) {
+        // every pixel under this tile is zero: all of its windows are background (prediction.rs:567-576)
+        if (a.dbg_flags)
+            for (int p = tid; p < npt; p += TRAV_THREADS) {
+                int gp = (ty * a.py + p / cx) * a.nx + tx * a.px + p % cx;
+                size_t o = (size_t)frame * a.nx * a.ny + gp;
+                a.dbg_flags[o] = 0;
+                if (a.dbg_leaf)
+                    for (int t = 0; t < T; ++t) a.dbg_leaf[o * T + t] = -1;
+            }
+        return;
+    }
+    // ---- phase 1b: column prefix sums in SEG row segments per column (local scans, then each segment
+    // adds the totals of the segments above it): ~fh/SEG + SEG dependent steps instead of fh
+    {
+        const int seg = max(1, min(8, TRAV_THREADS / fw));
+        const int rows = (fh + seg - 1) / seg;
+        const int units = fw * seg;                      // unit u = (segment u / fw, column 1 + u % fw)
+        for (int u = tid; u < units; u += TRAV_THREADS) {
+            const int sidx = u / fw;
+            uint32_t *col = sat + 1 + u % fw;
+            const int y0 = 1 + sidx * rows, y1 = min(fh, y0 + rows - 1);
+            uint32_t run = 0;
+#pragma unroll 4
+            for (int y = y0; y <= y1; ++y) { run += col[y * ss]; col[y * ss] = run; }
+        }
+        __syncthreads();
+        uint32_t off[4] = {0, 0, 0, 0};                  // fw <= 4096 -> at most 4 units per thread
+        if (seg > 1) {
+            int k = 0;
+            for (int u = tid; u < units; u += TRAV_THREADS, ++k) {
+                const int sidx = u / fw;
+                const uint32_t *col = sat + 1 + u % fw;
+                uint32_t o = 0;
+                for (int s2 = 0; s2 < sidx; ++s2) {
+                    int ye = min(fh, (s2 + 1) * rows);
+                    if (ye >= 1 + s2 * rows) o += col[ye * ss];
+                }
+                off[k & 3] = o;
+            }
+        }
+        __syncthreads();
+        if (seg > 1) {
+            int k = 0;
+            for (int u = tid; u < units; u += TRAV_THREADS, ++k) {
+                const int sidx = u / fw;
+                uint32_t *col = sat + 1 + u % fw;
+                const int y0 = 1 + sidx * rows, y1 = min(fh, y0 + rows - 1);
+                const uint32_t o = off[k & 3];
+                if (o)
+#pragma unroll 4
+                    for (int y = y0; y <= y1; ++y) col[y * ss] += o;
+            }
         }
     }
     __syncthreads();
@@ -364,14 +439,26 @@ __global__ void __launch_bounds__(TRAV_THREADS) k_traverse(TraverseArgs a) {
     if (my_hits) {
         uint32_t o = misc[3] + my_base;
         HitRec *dst = a.hits + (size_t)frame * a.hits_cap;
+        HitBox *dbox = a.hit_box + (size_t)frame * a.hits_cap;
+        HitRot *drot = a.hit_rot + (size_t)frame * a.hits_cap;
         float q0 = p3s[my_p * 3 + 0], q1 = p3s[my_p * 3 + 1], q2 = p3s[my_p * 3 + 2];
         for (int t = 0; t < T; ++t) {
             uint32_t lid = (uint32_t)leaf[my_p * T + t];
             uint32_t lf = a.f.leaf_flags[lid];
             if ((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF))) {
                 if (o < a.hits_cap) {
-                    float4 rec = make_float4(q0, q1, q2, __uint_as_float(lid));
-                    *(float4 *)(dst + o) = rec;
+                    const float *mn = a.f.off_min + (size_t)lid * 3, *mx = a.f.off_max + (size_t)lid * 3;
+                    const uint32_t v = a.f.leaf_v[lid];
+                    const uint32_t ob = a.f.off_begin[lid], n_off = a.f.off_begin[lid + 1] - ob;
+                    const uint32_t rb = a.f.rot_begin[lid], n_rot = a.f.rot_begin[lid + 1] - rb;
+                    *(float4 *)(dst + o) = make_float4(q0, q1, q2, __uint_as_float(ob));
+                    int4 b0 = make_int4(f32_as_i32(__fsub_rn(q0, mx[0])), f32_as_i32(__fsub_rn(q1, mx[1])),
+                                        f32_as_i32(__fsub_rn(q2, mx[2])), f32_as_i32(__fsub_rn(q0, mn[0])));
+                    int4 b1 = make_int4(f32_as_i32(__fsub_rn(q1, mn[1])), f32_as_i32(__fsub_rn(q2, mn[2])), (int)v,
+                                        (int)(lf | (n_off << 8)));
+                    ((int4 *)(dbox + o))[0] = b0;
+                    ((int4 *)(dbox + o))[1] = b1;
+                    *(uint4 *)(drot + o) = make_uint4((lf & LF_ROT) ? a.f.rbin_box[lid] : 0xFFFFFFFFu, a.f.rbin_box_hi[lid], rb, n_rot);
                 }
                 o++;
             }
@@ -413,17 +500,18 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
     for (int i = tid; i < DH_GRID3; i += VOTE_THREADS) rot[i] = 0;
     __syncthreads();
     const HitRec *hits = a.hits + (size_t)frame * a.hits_cap;
+    const HitBox *box = a.hit_box + (size_t)frame * a.hits_cap;
+    const HitRot *hr = a.hit_rot + (size_t)frame * a.hits_cap;
     const float wm1 = (float)(a.w - 1), hm1 = (float)(a.h - 1);
     for (uint32_t i = h0 + tid; i < h1; i += VOTE_THREADS) {
-        float4 rec = *(const float4 *)(hits + i);
-        uint32_t L = __float_as_uint(rec.w);
-        uint32_t lf = a.f.leaf_flags[L], v = a.f.leaf_v[L];
-        if (lf & LF_ROT) {
-            uint32_t rb = a.f.rot_begin[L], re = a.f.rot_begin[L + 1];
-            for (uint32_t r = rb; r < re; ++r) atomicAdd(&rot[a.f.rot_rough[r]], v);      // :636
-        }
-        if (lf & LF_OFF) {
-            uint32_t ob = a.f.off_begin[L], oe = a.f.off_begin[L + 1];
+        const float4 rec = *(const float4 *)(hits + i);
+        const int4 b1 = ((const int4 *)(box + i))[1];
+        const uint4 rr = *(const uint4 *)(hr + i);
+        const uint32_t v = (uint32_t)b1.z, fc = (uint32_t)b1.w;
+        if (fc & LF_ROT)
+            for (uint32_t r = rr.z; r < rr.z + rr.w; ++r) atomicAdd(&rot[a.f.rot_rough[r]], v);      // :636
+        if (fc & LF_OFF) {
+            const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
             for (uint32_t o = ob; o < oe; ++o) {
                 const float *of = a.f.offsets + (size_t)o * 3;
                 float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // :647
@@ -452,35 +540,38 @@ hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
 }
 
 // ================================================================== k_cluster
-// One workgroup per (frame, accumulator): blockIdx.x = 0 head position (`mid`), 1 rotation (`rot`).
+// One 1024-thread workgroup per (frame, accumulator): blockIdx.x = 0 head position (`mid`),
+// 1 rotation (`rot`).
 //
 // The reference keeps both accumulators as unbounded HashMap<(i32,i32,i32),u32>
-// (meanshift.rs:14-68) and reads a 20^3 window per iteration.  Here the window is rebuilt per
-// iteration straight from the hit records: every vote whose cell falls inside the window is added
-// to an LDS cell with an integer atomic (exact), leaves whose vote bounding box misses the window
-// are skipped with one test.  The weighted sums are then taken over the non-zero cells in the
-// reference's x -> y -> z order (meanshift.rs:344-381) as a strictly sequential f32 chain
-// (4 lanes: num.x, num.y, num.z, den); everything off that chain (cell compaction, kernel weight,
-// products) is done by all 256 threads.
-#define CL_THREADS 256
+// (meanshift.rs:14-68) and reads a 20^3 window per iteration.  Here a 26^3-cell REGION of the
+// accumulator around the current position is materialised in LDS straight from the hit records
+// (integer atomics: exact, order-free); hits whose vote bounding box misses the region are dropped
+// with one test.  The mean shift then iterates inside the region and the gather is repeated only
+// when the 20^3 window would leave it (it moves by a few cells per step after the first).
+// The weighted sums run over the non-zero window cells in the reference's x -> y -> z order
+// (meanshift.rs:344-381) as a strictly sequential f32 chain on 4 lanes (num.x, num.y, num.z, den);
+// everything off that chain (cell compaction, kernel weight, products) is done by all threads.
+#define CL_THREADS 1024
 #define CL_WAVES (CL_THREADS / WAVE)
-#define CL_CHUNKS 32            // 32 * 256 = 8192 >= 8000 window cells
-#define CL_PROD_CAP 2048        // products staged per pass (x4 floats = 32 KB)
+#define CL_CHUNKS 8             // 8 * 1024 = 8192 >= 8000 window cells
+#define CL_PROD_CAP 512         // products staged per pass (x4 floats = 8 KB)
+#define RG 26                   // region edge; the window may sit at offsets 0..RG-20 inside it
+#define RG3 (RG * RG * RG)
 
-__device__ __forceinline__ bool window_hits_range(int32_t lo, int32_t hi, int32_t pos) {
-    // exists cell in [lo,hi] and d in [-10,9] with cell == pos + d (i32 wrapping, as the reference's
-    // release-mode `pos + offset`)?
-    uint32_t len = (uint32_t)hi - (uint32_t)lo;
-    uint32_t u = (uint32_t)pos - 10u - (uint32_t)lo;
-    return u <= len || u >= (uint32_t)(-19);
+// exists c in [lo,hi] and d in [0,len) with c == start + d (i32 wrapping, like the reference's
+// release-mode `pos + offset`)?
+__device__ __forceinline__ bool range_hits_span(int32_t lo, int32_t hi, int32_t start, uint32_t len) {
+    uint32_t u = (uint32_t)start - (uint32_t)lo;
+    return u <= (uint32_t)hi - (uint32_t)lo || u >= (uint32_t)(1u - len);
 }
 
-__global__ void __launch_bounds__(CL_THREADS) k_cluster(ClusterArgs a) {
-    __shared__ uint32_t win[CL_CHUNKS * CL_THREADS];
+__global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
+    __shared__ uint32_t region[RG3];
     __shared__ __attribute__((aligned(16))) float prod[CL_PROD_CAP * 4];
     __shared__ uint32_t cnt[CL_CHUNKS * CL_WAVES];
-    __shared__ unsigned long long red64[CL_WAVES * 2];
-    __shared__ uint32_t red32[CL_WAVES * 2];
+    __shared__ unsigned long long red64[CL_WAVES];
+    __shared__ uint32_t red32[CL_WAVES];
     __shared__ int32_t s_pos[3];
     __shared__ float s_acc[4];
     __shared__ uint32_t s_total;
@@ -488,65 +579,56 @@ __global__ void __launch_bounds__(CL_THREADS) k_cluster(ClusterArgs a) {
     const int which = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const uint8_t gmask = a.guess_mask ? a.guess_mask[frame] : 3;
 
-    // ---------------- initial guess
-    if (which == 0) {
-        // first strictly-greatest cell of the 20x20 grid, start (max=0, idx=0) (prediction.rs:694-702)
-        const uint32_t *g = a.pos_grid + (size_t)frame * DH_POSGRID;
-        unsigned long long best = 0;   // (value << 32) | (~idx): max picks greatest value, then smallest idx
-        for (int i = tid; i < DH_POSGRID; i += CL_THREADS) {
-            unsigned long long k = ((unsigned long long)g[i] << 32) | (uint32_t)(~(uint32_t)i);
-            if (g[i] && k > best) best = k;
+    // ---------------- initial guess: first strictly-greatest cell, i.e. greatest value then smallest
+    // index (prediction.rs:694-702 for the 20x20 grid; :733-742 with the x-fastest iteration order of
+    // meanshift.rs:114-138 for the 20^3 grid); all-zero grid -> index 0
+    {
+        const uint32_t *g = which == 0 ? a.pos_grid + (size_t)frame * DH_POSGRID : a.rot_grid + (size_t)frame * DH_GRID3;
+        const int ncell = which == 0 ? DH_POSGRID : DH_GRID3;
+        unsigned long long best = 0;   // (value << 32) | ~idx
+        for (int i = tid; i < ncell; i += CL_THREADS) {
+            uint32_t gv = g[i];
+            unsigned long long k = ((unsigned long long)gv << 32) | (uint32_t)(~(uint32_t)i);
+            if (gv && k > best) best = k;
         }
         for (int d = WAVE / 2; d; d >>= 1) { unsigned long long o = __shfl_down(best, d); if (o > best) best = o; }
         if (lane == 0) red64[wave] = best;
         __syncthreads();
         best = red64[0];
         for (int i = 1; i < CL_WAVES; ++i) if (red64[i] > best) best = red64[i];
-        int best_idx = best ? (int)(~(uint32_t)best) : 0;
-        int gpw = a.w / DH_GRID, gph = a.h / DH_GRID;                 // :706-707
-        int mxg = best_idx % DH_GRID, myg = best_idx / DH_GRID;       // :708-709
-        // mean of the non-zero pixels of that image cell (:711-725)
-        const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
-        unsigned long long zs = 0; uint32_t zc = 0;
-        for (int i = tid; i < gpw * gph; i += CL_THREADS) {
-            int xx = gpw * mxg + i % gpw, yy = gph * myg + i / gpw;
-            uint32_t v = img[(size_t)yy * a.w + xx];
-            if (v) { zs += v; zc++; }
-        }
-        for (int d = WAVE / 2; d; d >>= 1) { zs += __shfl_down(zs, d); zc += __shfl_down(zc, d); }
+        const uint32_t best_idx = best ? ~(uint32_t)best : 0u;
         __syncthreads();
-        if (lane == 0) { red64[wave] = zs; red32[wave] = zc; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 1; i < CL_WAVES; ++i) { zs += red64[i]; zc += red32[i]; }
-            float meanz = zc ? (float)__ddiv_rn((double)zs, (double)zc) : 0.0f;
-            float mx = __fmul_rn(__fadd_rn((float)mxg, 0.5f), (float)gpw);       // :727-728
-            float my = __fmul_rn(__fadd_rn((float)myg, 0.5f), (float)gph);
-            float q[3];
-            to3d(a.kinv, mx, my, meanz, q);                                       // :729
-            int32_t gm[3] = {f32_as_i32(q[0]), f32_as_i32(q[1]), f32_as_i32(q[2]) / DH_ZSCALEFACTOR};  // :750
-            if (a.midp_guess && (gmask & 1)) {                                    // :437-441
-                const float *mg = a.midp_guess + (size_t)frame * 3;
-                gm[0] = f32_as_i32(mg[0]); gm[1] = f32_as_i32(mg[1]); gm[2] = f32_as_i32(mg[2]) / DH_ZSCALEFACTOR;
+        if (which == 0) {
+            int gpw = a.w / DH_GRID, gph = a.h / DH_GRID;                 // :706-707
+            int mxg = best_idx % DH_GRID, myg = best_idx / DH_GRID;       // :708-709
+            // mean of the non-zero pixels of that image cell (:711-725)
+            const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
+            unsigned long long zs = 0; uint32_t zc = 0;
+            for (int i = tid; i < gpw * gph; i += CL_THREADS) {
+                int xx = gpw * mxg + i % gpw, yy = gph * myg + i / gpw;
+                uint32_t v = img[(size_t)yy * a.w + xx];
+                if (v) { zs += v; zc++; }
             }
-            s_pos[0] = gm[0]; s_pos[1] = gm[1]; s_pos[2] = gm[2];
-        }
-    } else {
-        // first strictly-greatest non-zero cell in x-fastest order (prediction.rs:733-742, meanshift.rs:114-138)
-        const uint32_t *g = a.rot_grid + (size_t)frame * DH_GRID3;
-        unsigned long long best = 0;
-        for (int i = tid; i < DH_GRID3; i += CL_THREADS) {
-            unsigned long long k = ((unsigned long long)g[i] << 32) | (uint32_t)(~(uint32_t)i);
-            if (g[i] && k > best) best = k;
-        }
-        for (int d = WAVE / 2; d; d >>= 1) { unsigned long long o = __shfl_down(best, d); if (o > best) best = o; }
-        if (lane == 0) red64[wave] = best;
-        __syncthreads();
-        if (tid == 0) {
-            best = red64[0];
-            for (int i = 1; i < CL_WAVES; ++i) if (red64[i] > best) best = red64[i];
-            uint32_t idx = best ? ~(uint32_t)best : 0u;
-            uint32_t rb[3] = {idx % DH_GRID, (idx / DH_GRID) % DH_GRID, idx / (DH_GRID * DH_GRID)};
+            for (int d = WAVE / 2; d; d >>= 1) { zs += __shfl_down(zs, d); zc += __shfl_down(zc, d); }
+            if (lane == 0) { red64[wave] = zs; red32[wave] = zc; }
+            __syncthreads();
+            if (tid == 0) {
+                zs = 0; zc = 0;
+                for (int i = 0; i < CL_WAVES; ++i) { zs += red64[i]; zc += red32[i]; }
+                float meanz = zc ? (float)__ddiv_rn((double)zs, (double)zc) : 0.0f;
+                float mx = __fmul_rn(__fadd_rn((float)mxg, 0.5f), (float)gpw);       // :727-728
+                float my = __fmul_rn(__fadd_rn((float)myg, 0.5f), (float)gph);
+                float q[3];
+                to3d(a.kinv, mx, my, meanz, q);                                       // :729
+                int32_t gm[3] = {f32_as_i32(q[0]), f32_as_i32(q[1]), f32_as_i32(q[2]) / DH_ZSCALEFACTOR};  // :750
+                if (a.midp_guess && (gmask & 1)) {                                    // :437-441
+                    const float *mg = a.midp_guess + (size_t)frame * 3;
+                    gm[0] = f32_as_i32(mg[0]); gm[1] = f32_as_i32(mg[1]); gm[2] = f32_as_i32(mg[2]) / DH_ZSCALEFACTOR;
+                }
+                s_pos[0] = gm[0]; s_pos[1] = gm[1]; s_pos[2] = gm[2];
+            }
+        } else if (tid == 0) {
+            uint32_t rb[3] = {best_idx % DH_GRID, (best_idx / DH_GRID) % DH_GRID, best_idx / (DH_GRID * DH_GRID)};
             for (int k = 0; k < 3; ++k) {
                 double deg = __ddiv_rn(__dadd_rn(__dmul_rn((double)rb[k], 360.0), 180.0), 20.0);   // :745-747
                 if (a.rot_guess && (gmask & 2))                                                   // :444-453
@@ -565,55 +647,93 @@ __global__ void __launch_bounds__(CL_THREADS) k_cluster(ClusterArgs a) {
     uint32_t n_hits = a.hit_count[frame];
     if (n_hits > a.hits_cap) n_hits = a.hits_cap;
     const HitRec *hits = a.hits + (size_t)frame * a.hits_cap;
+    const HitBox *box = a.hit_box + (size_t)frame * a.hits_cap;
+    const HitRot *hr = a.hit_rot + (size_t)frame * a.hits_cap;
+    int32_t org[3] = {0, 0, 0};     // region origin (cell coordinates of region[0])
+    bool have_region = false;
     uint32_t steps = 0;
     for (uint32_t it = 0; it < a.iterations; ++it) {
-        for (int i = tid; i < CL_CHUNKS * CL_THREADS; i += CL_THREADS) win[i] = 0;
-        __syncthreads();
-        // ---- window gather
-        for (uint32_t i = tid; i < n_hits; i += CL_THREADS) {
-            float4 rec = *(const float4 *)(hits + i);
-            uint32_t L = __float_as_uint(rec.w);
-            uint32_t lf = a.f.leaf_flags[L];
+        // window offset inside the region; the region is valid while 0 <= woff <= RG-20 on every axis
+        uint32_t wo0 = (uint32_t)pos[0] - 10u - (uint32_t)org[0], wo1 = (uint32_t)pos[1] - 10u - (uint32_t)org[1],
+                 wo2 = (uint32_t)pos[2] - 10u - (uint32_t)org[2];
+        if (!have_region || wo0 > RG - 20 || wo1 > RG - 20 || wo2 > RG - 20) {
+            // ---- (re)build the region centred on the window
+            for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)pos[k] - 10u - (uint32_t)((RG - 20) / 2));
+            wo0 = wo1 = wo2 = (RG - 20) / 2;
+            have_region = true;
+            __syncthreads();                       // previous iteration's readers are done
+            for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
+            __syncthreads();
             if (which == 0) {
-                if (!(lf & LF_OFF)) continue;
-                const float *mn = a.f.off_min + (size_t)L * 3, *mx = a.f.off_max + (size_t)L * 3;
-                // cell_k = trunc(p_k - o_k) is monotone in o_k, so it lies in [trunc(p-omax), trunc(p-omin)]
-                if (!window_hits_range(f32_as_i32(__fsub_rn(rec.x, mx[0])), f32_as_i32(__fsub_rn(rec.x, mn[0])), pos[0])) continue;
-                if (!window_hits_range(f32_as_i32(__fsub_rn(rec.y, mx[1])), f32_as_i32(__fsub_rn(rec.y, mn[1])), pos[1])) continue;
-                if (!window_hits_range(f32_as_i32(__fsub_rn(rec.z, mx[2])), f32_as_i32(__fsub_rn(rec.z, mn[2])), pos[2])) continue;
-                uint32_t v = a.f.leaf_v[L];
-                uint32_t ob = a.f.off_begin[L], oe = a.f.off_begin[L + 1];
-                for (uint32_t o = ob; o < oe; ++o) {
-                    const float *of = a.f.offsets + (size_t)o * 3;
-                    float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // prediction.rs:647
-                    if (nz < 0.0f) continue;                                                                      // :650
-                    uint32_t dx = (uint32_t)f32_as_i32(nx) - (uint32_t)pos[0] + 10u;                              // :667
-                    uint32_t dy = (uint32_t)f32_as_i32(ny) - (uint32_t)pos[1] + 10u;
-                    uint32_t dz = (uint32_t)f32_as_i32(__fdiv_rn(nz, (float)DH_ZSCALEFACTOR)) - (uint32_t)pos[2] + 10u;
-                    if (dx < 20u && dy < 20u && dz < 20u) atomicAdd(&win[(dx * 20u + dy) * 20u + dz], v);
+                for (uint32_t i0 = 0; i0 < n_hits; i0 += CL_THREADS * 2) {
+                    int4 b0[2], b1[2];
+                    float4 rec[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        uint32_t i = i0 + j * CL_THREADS + tid;
+                        b1[j].w = 0;
+                        if (i < n_hits) { b0[j] = ((const int4 *)(box + i))[0]; b1[j] = ((const int4 *)(box + i))[1]; rec[j] = *(const float4 *)(hits + i); }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t fc = (uint32_t)b1[j].w;
+                        if (!(fc & LF_OFF)) continue;
+                        if (!range_hits_span(b0[j].x, b0[j].w, org[0], RG)) continue;
+                        if (!range_hits_span(b0[j].y, b1[j].x, org[1], RG)) continue;
+                        if (!range_hits_span(b0[j].z, b1[j].y, org[2], RG)) continue;
+                        const uint32_t v = (uint32_t)b1[j].z, ob = __float_as_uint(rec[j].w), oe = ob + (fc >> 8);
+                        for (uint32_t o = ob; o < oe; ++o) {
+                            const float *of = a.f.offsets + (size_t)o * 3;
+                            float nx = __fsub_rn(rec[j].x, of[0]), ny = __fsub_rn(rec[j].y, of[1]), nz = __fsub_rn(rec[j].z, of[2]); // prediction.rs:647
+                            if (nz < 0.0f) continue;                                                                      // :650
+                            uint32_t dx = (uint32_t)f32_as_i32(nx) - (uint32_t)org[0];                                     // :667
+                            uint32_t dy = (uint32_t)f32_as_i32(ny) - (uint32_t)org[1];
+                            uint32_t dz = (uint32_t)f32_as_i32(__fdiv_rn(nz, (float)DH_ZSCALEFACTOR)) - (uint32_t)org[2];
+                            if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], v);
+                        }
+                    }
                 }
             } else {
-                if (!(lf & LF_ROT)) continue;
-                uint32_t bl = a.f.rbin_box[L], bh = a.f.rbin_box_hi[L];
-                if (!window_hits_range((int32_t)(bl & 255u), (int32_t)(bh & 255u), pos[0])) continue;
-                if (!window_hits_range((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), pos[1])) continue;
-                if (!window_hits_range((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), pos[2])) continue;
-                uint32_t v = a.f.leaf_v[L];
-                uint32_t rb = a.f.rot_begin[L], re = a.f.rot_begin[L + 1];
-                for (uint32_t r = rb; r < re; ++r) {
-                    uint32_t b = a.f.rot_bin[r];                                                                  // prediction.rs:635
-                    uint32_t dx = (b & 255u) - (uint32_t)pos[0] + 10u;
-                    uint32_t dy = ((b >> 8) & 255u) - (uint32_t)pos[1] + 10u;
-                    uint32_t dz = ((b >> 16) & 255u) - (uint32_t)pos[2] + 10u;
-                    if (dx < 20u && dy < 20u && dz < 20u) atomicAdd(&win[(dx * 20u + dy) * 20u + dz], v);
+                for (uint32_t i0 = 0; i0 < n_hits; i0 += CL_THREADS * 2) {
+                    uint4 r[2];
+                    uint32_t vv[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        uint32_t i = i0 + j * CL_THREADS + tid;
+                        r[j].x = 0xFFFFFFFFu;
+                        if (i < n_hits) { r[j] = *(const uint4 *)(hr + i); vv[j] = box[i].v; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t bl = r[j].x, bh = r[j].y;
+                        if (bl == 0xFFFFFFFFu) continue;
+                        if (!range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG)) continue;
+                        if (!range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG)) continue;
+                        if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG)) continue;
+                        const uint32_t v = vv[j];
+                        for (uint32_t q = r[j].z; q < r[j].z + r[j].w; ++q) {
+                            uint32_t b = a.f.rot_bin[q];                                                                  // prediction.rs:635
+                            uint32_t dx = (b & 255u) - (uint32_t)org[0];
+                            uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
+                            uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
+                            if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], v);
+                        }
+                    }
                 }
             }
         }
         __syncthreads();
-        // ---- order-preserving compaction of the non-zero cells: cell index = chunk*256 + tid
-#pragma unroll 4
+        // ---- order-preserving compaction of the window's non-zero cells; window cell index
+        // (dx*20+dy)*20+dz = chunk*1024 + tid is the reference's summation order
+#pragma unroll 1
         for (int c = 0; c < CL_CHUNKS; ++c) {
-            uint64_t b = __ballot(win[c * CL_THREADS + tid] != 0);
+            const uint32_t cell = (uint32_t)(c * CL_THREADS + tid);
+            uint32_t fv = 0;
+            if (cell < DH_GRID3) {
+                uint32_t dz = cell % 20u, dy = (cell / 20u) % 20u, dx = cell / 400u;
+                fv = region[((wo0 + dx) * RG + wo1 + dy) * RG + wo2 + dz];
+            }
+            uint64_t b = __ballot(fv != 0);
             if (lane == 0) cnt[c * CL_WAVES + wave] = (uint32_t)__popcll(b);
         }
         __syncthreads();
@@ -629,21 +749,20 @@ __global__ void __launch_bounds__(CL_THREADS) k_cluster(ClusterArgs a) {
         __syncthreads();
         const uint32_t total = s_total;
         for (uint32_t base = 0; base < total; base += CL_PROD_CAP) {
-#pragma unroll 2
+#pragma unroll 1
             for (int c = 0; c < CL_CHUNKS; ++c) {
-                const uint32_t fc = win[c * CL_THREADS + tid];
-                uint64_t b = __ballot(fc != 0);
-                if (fc) {
+                const uint32_t cell = (uint32_t)(c * CL_THREADS + tid);
+                const uint32_t dz = cell % 20u, dy = (cell / 20u) % 20u, dx = cell / 400u;
+                const uint32_t fv = cell < DH_GRID3 ? region[((wo0 + dx) * RG + wo1 + dy) * RG + wo2 + dz] : 0u;
+                uint64_t b = __ballot(fv != 0);
+                if (fv) {
                     uint32_t k = cnt[c * CL_WAVES + wave] + (uint32_t)__popcll(b & lanemask_lt());
                     if (k >= base && k < base + CL_PROD_CAP) {
-                        uint32_t cell = (uint32_t)(c * CL_THREADS + tid);
-                        uint32_t dz = cell % 20u, dy = (cell / 20u) % 20u, dx = cell / 400u;
-                        float w = __fmul_rn(a.kern_ord[cell], (float)fc);                   // meanshift.rs:370-379
+                        float w = __fmul_rn(a.kern_ord[cell], (float)fv);                   // meanshift.rs:370-379
                         float ax = (float)(int32_t)((uint32_t)pos[0] + dx - 10u);           // :373-375
                         float ay = (float)(int32_t)((uint32_t)pos[1] + dy - 10u);
                         float az = (float)(int32_t)((uint32_t)pos[2] + dz - 10u);
-                        float4 pr = make_float4(__fmul_rn(ax, w), __fmul_rn(ay, w), __fmul_rn(az, w), w);
-                        *(float4 *)(prod + (k - base) * 4) = pr;
+                        *(float4 *)(prod + (k - base) * 4) = make_float4(__fmul_rn(ax, w), __fmul_rn(ay, w), __fmul_rn(az, w), w);
                     }
                 }
             }
@@ -664,17 +783,16 @@ __global__ void __launch_bounds__(CL_THREADS) k_cluster(ClusterArgs a) {
             }
             __syncthreads();
         }
-        float den = s_acc[3];
+        const float den = s_acc[3];
         if (den == 0.0f) break;                                                              // :385-388
         int32_t np0 = f32_as_i32(__fdiv_rn(s_acc[0], den)), np1 = f32_as_i32(__fdiv_rn(s_acc[1], den)),
                 np2 = f32_as_i32(__fdiv_rn(s_acc[2], den));                                   // :391-394
-        bool fixed = np0 == pos[0] && np1 == pos[1] && np2 == pos[2];
+        const bool fixed = np0 == pos[0] && np1 == pos[1] && np2 == pos[2];
         pos[0] = np0; pos[1] = np1; pos[2] = np2;
         steps++;
         if (trace && tid < 3) trace[steps * 3 + tid] = pos[tid];
-        __syncthreads();   // s_acc / win are rewritten next iteration
         if (fixed) {
-            // a fixed point: every remaining iteration recomputes the same window and the same
+            // a fixed point: every remaining iteration sees the same window and returns the same
             // position, so the reference's result (and trace) is this position repeated
             if (trace && tid < 3)
                 for (uint32_t s2 = steps + 1; s2 <= a.iterations; ++s2) trace[s2 * 3 + tid] = pos[tid];
@@ -710,12 +828,14 @@ __global__ void __launch_bounds__(256) k_votes_dump(VotesDumpArgs a) {
     uint32_t n = a.hit_count[a.frame];
     if (n > a.hits_cap) n = a.hits_cap;
     const HitRec *hits = a.hits + (size_t)a.frame * a.hits_cap;
+    const HitBox *box = a.hit_box + (size_t)a.frame * a.hits_cap;
+    const HitRot *hr = a.hit_rot + (size_t)a.frame * a.hits_cap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float4 rec = *(const float4 *)(hits + i);
-        uint32_t L = __float_as_uint(rec.w);
-        uint32_t lf = a.f.leaf_flags[L], v = a.f.leaf_v[L];
-        if (a.which == 0 && (lf & LF_OFF)) {
-            for (uint32_t o = a.f.off_begin[L]; o < a.f.off_begin[L + 1]; ++o) {
+        const float4 rec = *(const float4 *)(hits + i);
+        const uint32_t v = box[i].v, fc = box[i].fc;
+        if (a.which == 0 && (fc & LF_OFF)) {
+            const uint32_t ob = __float_as_uint(rec.w);
+            for (uint32_t o = ob; o < ob + (fc >> 8); ++o) {
                 const float *of = a.f.offsets + (size_t)o * 3;
                 float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]);
                 if (nz < 0.0f) continue;
@@ -725,8 +845,8 @@ __global__ void __launch_bounds__(256) k_votes_dump(VotesDumpArgs a) {
                     a.out[k * 4 + 2] = f32_as_i32(__fdiv_rn(nz, (float)DH_ZSCALEFACTOR)); a.out[k * 4 + 3] = (int32_t)v;
                 }
             }
-        } else if (a.which == 1 && (lf & LF_ROT)) {
-            for (uint32_t r = a.f.rot_begin[L]; r < a.f.rot_begin[L + 1]; ++r) {
+        } else if (a.which == 1 && (fc & LF_ROT)) {
+            for (uint32_t r = hr[i].rb; r < hr[i].rb + hr[i].n_rot; ++r) {
                 uint32_t b = a.f.rot_bin[r];
                 uint32_t k = atomicAdd(a.count, 1u);
                 if (k < a.cap) {
