@@ -46,6 +46,8 @@ struct dh_forest {
     std::vector<double> rotations;
     uint32_t max_depth = 0;
     uint16_t max_x = 0, max_y = 0;   // largest rectangle corner used by any node
+    bool uniform = false;            // every split rectangle has the same non-empty size
+    uint16_t rw = 0, rh = 0;
 };
 
 static inline int32_t rot_bin_host(double deg) {
@@ -126,6 +128,15 @@ extern "C" int dh_forest_create(const dh_forest_desc *d, dh_forest **out) {
     for (uint32_t L = 0; L < NL; ++L)
         if (f->off_begin[L + 1] - f->off_begin[L] >= (1u << 24) || f->rot_begin[L + 1] - f->rot_begin[L] >= (1u << 24))
             return bad(DH_EFOREST, "leaf %ld: more than 2^24 votes", L);
+    // ---- one rectangle size for the whole forest? (the in-tree trainer's geometry)
+    if (NN > 0) {
+        const dh_node &n0 = f->nodes[0];
+        f->rw = (uint16_t)(n0.r1[2] - n0.r1[0]); f->rh = (uint16_t)(n0.r1[3] - n0.r1[1]);
+        f->uniform = f->rw > 0 && f->rh > 0;
+        for (uint32_t i = 0; i < NN && f->uniform; ++i)
+            for (const uint16_t *rc : {f->nodes[i].r1, f->nodes[i].r2})
+                if (rc[2] - rc[0] != f->rw || rc[3] - rc[1] != f->rh) f->uniform = false;
+    }
     // ---- leaves that can vote
     for (uint32_t L = 0; L < NL; ++L) {
         if (!(f->leaf_prob[L] > 0.0)) continue;
@@ -160,7 +171,8 @@ extern "C" int dh_forest_info(const dh_forest *f, uint32_t *n_trees, uint32_t *n
 // ------------------------------------------------------------------ geometry
 struct Geom {
     int w = 0, h = 0, nx = 0, ny = 0, npatch = 0;
-    int px = 0, py = 0, tiles_x = 0, tiles_y = 0, ss_max = 0;
+    int px = 0, py = 0, tiles_x = 0, tiles_y = 0, ss_max = 0, ss_row = 0;
+    bool uniform = false;
     size_t lds = 0;
 };
 
@@ -190,6 +202,10 @@ struct dh_predictor {
     DevForest dev{};
     std::vector<void *> forest_allocs;
     float *kern_ord = nullptr;   // device, 8000 floats
+    bool f_uniform = false;      // forest has one split-rectangle size
+    int f_rw = 0, f_rh = 0;
+    void *nodes_u = nullptr;     // 16-byte compact nodes for the current ss_row (uniform path)
+    int nodes_u_ss = 0;
     hipStream_t own_stream = nullptr;
     // workspace
     Geom geom;
@@ -315,6 +331,7 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     p->params = *prm;
     p->n_trees = (uint32_t)f->roots.size(); p->n_nodes = (uint32_t)f->nodes.size(); p->n_leaves = (uint32_t)f->leaf_prob.size();
     p->n_off = f->off_begin.back(); p->n_rot = f->rot_begin.back(); p->max_depth = f->max_depth;
+    p->f_uniform = f->uniform; p->f_rw = f->rw; p->f_rh = f->rh;
     int rc = DH_OK;
     DevForest &d = p->dev;
     d.n_trees = p->n_trees; d.n_nodes = p->n_nodes; d.n_leaves = p->n_leaves; d.n_off = p->n_off; d.n_rot = p->n_rot;
@@ -335,6 +352,7 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     STEP(dev_alloc(p, &d.rbin_box, p->n_leaves, true));
     STEP(dev_alloc(p, &d.rbin_box_hi, p->n_leaves, true));
     STEP(dev_alloc(p, &p->kern_ord, DH_GRID3));
+    { uint4 *nu = nullptr; STEP(dev_alloc(p, &nu, p->n_nodes, true)); p->nodes_u = nu; }
 #undef STEP
     auto hipstep = [&](hipError_t e, const char *what) {
         if (rc == DH_OK && e != hipSuccess) rc = fail(DH_EHIP, "%s: %s", what, hipGetErrorString(e));
@@ -397,7 +415,8 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
     }
     g.tiles_x = (g.nx + g.px - 1) / g.px;
     g.tiles_y = (g.ny + g.py - 1) / g.py;
-    g.ss_max = ((g.px - 1) * step + sw + 1) * ((g.py - 1) * step + sh + 1);
+    g.ss_row = (((g.px - 1) * step + sw) + 1) | 1;
+    g.ss_max = g.ss_row * ((g.py - 1) * step + sh + 1);
     return DH_OK;
 }
 
@@ -438,6 +457,17 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     }
 #undef STEP
     if (rc != DH_OK) { free_workspace(p); return rc; }
+    // uniform-rectangle fast path: box sums fit i32, packed LDS offsets fit 14 bits
+    if (g.npatch > 0) {
+        const long max_off = (long)((int)p->params.subimage_height - p->f_rh) * g.ss_row + ((int)p->params.subimage_width - p->f_rw);
+        g.uniform = p->f_uniform && (long)p->f_rw * p->f_rh <= 32768 && max_off < 16384 && !getenv("DH_FORCE_GENERAL");
+        if (g.uniform && p->nodes_u_ss != g.ss_row) {
+            hipError_t e = dh_launch_nodes_compact(p->dev, g.ss_row, (uint32_t)(p->f_rw * p->f_rh), p->nodes_u, p->own_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(p->own_stream);
+            if (e != hipSuccess) { free_workspace(p); return fail(DH_EHIP, "k_nodes_compact: %s", hipGetErrorString(e)); }
+            p->nodes_u_ss = g.ss_row;
+        }
+    }
     p->geom = g;
     p->cap_frames = cap;
     return DH_OK;
@@ -474,7 +504,10 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
         ta.step = (int)p->params.stepwidth; ta.sw = (int)p->params.subimage_width; ta.sh = (int)p->params.subimage_height;
         ta.lw = ta.sw / 2; ta.lh = ta.sh / 2;
         ta.nx = g.nx; ta.ny = g.ny; ta.px = g.px; ta.py = g.py; ta.tiles_x = g.tiles_x; ta.tiles_y = g.tiles_y;
-        ta.ss_max = g.ss_max;
+        ta.ss_max = g.ss_max; ta.ss_row = g.ss_row;
+        ta.uniform = g.uniform ? 1 : 0; ta.rw = p->f_rw; ta.rh = p->f_rh; ta.area = (uint32_t)(p->f_rw * p->f_rh);
+        ta.nodes_u = p->nodes_u;
+        if (const char *e = getenv("DH_TRAV_STOP")) ta.stop_phase = atoi(e);
         memcpy(ta.kinv, kinv, sizeof kinv);
         ta.f = p->dev;
         ta.hits = p->hits; ta.hit_box = p->hit_box; ta.hit_rot = p->hit_rot; ta.hit_count = hit_count; ta.hits_cap = p->hits_cap;

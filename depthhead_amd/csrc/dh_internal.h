@@ -70,6 +70,12 @@ struct TraverseArgs {
     int px, py;             // tile size in patches
     int tiles_x, tiles_y;
     int ss_max;             // LDS SAT capacity in words
+    int ss_row;             // SAT row stride in words (odd), the same for every tile
+    int uniform;            // 1: every split rectangle is rw x rh -> box-sum fast path
+    int rw, rh;
+    uint32_t area;          // rw * rh
+    const void *nodes_u;    // NodeU[n_nodes], built by k_nodes_compact for this ss_row
+    int stop_phase;         // profiling knob (env DH_TRAV_STOP): 0 = run everything, k = return after phase k
     float kinv[9];
     DevForest f;
     HitRec   *hits;
@@ -132,6 +138,7 @@ struct VotesDumpArgs {
 
 // launchers (dh_kernels.hip)
 hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s);
+hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, uint32_t area, void *out, hipStream_t s);
 hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s);
 hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s);
 hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s);

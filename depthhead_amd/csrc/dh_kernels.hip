@@ -168,27 +168,85 @@ hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ================================================================== k_nodes_compact
+// Geometry-specific 16-byte node table for the uniform-rectangle fast path of k_traverse.
+//
+// When every split rectangle of the forest has the same size rw x rh (the in-tree trainer's
+// geometry: one scale factor, hough_tree_trainer.rs:165 / prediction.rs:82-86), c1 == c2 == c and
+//     avg1 - avg2 > thr   with   avg_i = fl(s_i / c),  d = fl(avg1 - avg2)
+// can be decided from the INTEGER D = s1 - s2:  delta = D / c is the real difference and
+// |d - delta| < 3 * 2^16 * 2^-53 < 2^-35 (each quotient is < 2^16 with relative error <= 2^-53, the
+// subtraction adds one more).  So  delta >= thr + 2^-34  =>  d > thr  and  delta <= thr - 2^-34
+// =>  d <= thr.  Per node: ilo = floor((thr - 2^-34) c - 2^-20), ihi = ceil((thr + 2^-34) c + 2^-20)
+// (the 2^-20 pad covers the rounding of these two products); D <= ilo -> Binar::Zero, D >= ihi ->
+// Binar::One, and the at most `amb` integers in between take the exact f64 path.
+struct __attribute__((aligned(16))) NodeU {
+    uint32_t offs;      // LDS offset of r1's box sum | r2's << 14 | amb << 28, relative to the patch origin
+    int32_t  ilo;
+    int32_t  child_zero;
+    int32_t  child_one;
+};
+
+__global__ void __launch_bounds__(256) k_nodes_compact(const dh_node *nodes, uint32_t n, int ss, uint32_t area, NodeU *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dh_node nd = nodes[i];
+    const double c = (double)area, thr = nd.threshold;
+    int32_t ilo;
+    uint32_t amb = 0;
+    if (thr >= 65535.0) {              // avg1 - avg2 <= 65535: never greater
+        ilo = INT32_MAX - 16;
+    } else if (thr < -65535.0) {       // avg1 - avg2 >= -65535: always greater
+        ilo = INT32_MIN;
+    } else {
+        const double m = 5.820766091346741e-11;   // 2^-34
+        const double pad = 9.5367431640625e-07;    // 2^-20
+        double lo = floor(__dsub_rn(__dmul_rn(__dsub_rn(thr, m), c), pad));
+        double hi = ceil(__dadd_rn(__dmul_rn(__dadd_rn(thr, m), c), pad));
+        long long l = (long long)lo, h = (long long)hi;      // |thr * c| <= 65535 * 32768 < 2^31 - 2^15
+        ilo = (int32_t)l;
+        amb = (uint32_t)(h - l - 1);                            // 0..2
+    }
+    NodeU o;
+    uint32_t o1 = (uint32_t)nd.r1[1] * (uint32_t)ss + nd.r1[0], o2 = (uint32_t)nd.r2[1] * (uint32_t)ss + nd.r2[0];
+    o.offs = o1 | (o2 << 14) | (amb << 28);
+    o.ilo = ilo;
+    o.child_zero = nd.child_zero;
+    o.child_one = nd.child_one;
+    out[i] = o;
+}
+
+hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, uint32_t area, void *out, hipStream_t s) {
+    if (f.n_nodes == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_nodes_compact, dim3((f.n_nodes + 255) / 256), dim3(256), 0, s, f.nodes, f.n_nodes, ss, area, (NodeU *)out);
+    return hipGetLastError();
+}
+
 // ================================================================== k_traverse
 // One 1024-thread workgroup per tile of PX x PY sliding-window positions of one frame.
 //
-// LDS: [ SAT (fh+1)x(fw+1) u32 | leaf ids npt*T i32 | p3 npt*3 f32 | active list npt u32 | misc ]
+// LDS: [ SAT (fh+1) x ss u32 | leaf ids npt*T i32 | p3 npt*3 f32 | active list npt u32 | misc ]
 //
 // The summed-area table is kept modulo 2^32: any rectangle inside a patch sums to
 // < sw*sh*65535 < 2^32 (checked at predictor creation), so differences are exact and one rect
 // mean costs 4 LDS reads instead of the reference's O(area) pixel loop (types.rs:317-339).
+// UNI = true: all split rectangles share one size; after the background gate the SAT is converted
+// in place into the image of rw x rh box sums, so a node costs 2 LDS reads and an integer compare.
 #define TRAV_THREADS 1024
 #define TRAV_WAVES (TRAV_THREADS / WAVE)
-#define ROWS_IN_FLIGHT 4
+#define ROWS_IN_FLIGHT 8
 
 size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees) {
     size_t fw = (size_t)(px - 1) * step + sw, fh = (size_t)(py - 1) * step + sh;
+    size_t ss = (fw + 1) | 1;      // odd row stride: row-per-lane LDS passes are bank-conflict free
     size_t npt = (size_t)px * py;
-    return ((fw + 1) * (fh + 1) + npt * n_trees + npt * 3 + npt + 16) * 4;   // keep in step with the carve-up in k_traverse
+    return (ss * (fh + 1) + npt * n_trees + npt * 3 + npt + 16) * 4;   // keep in step with the carve-up in k_traverse
 }
 
+template <bool UNI>
 __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int T = (int)a.f.n_trees;
 
     // XCD-aware block -> (frame, tile): blocks b and b+8 share an XCD (and its L2), so one XCD
@@ -203,70 +261,65 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     const int npt = cx * cy;
     const int fx0 = tx * a.px * a.step, fy0 = ty * a.py * a.step;   // footprint origin (pixels)
     const int fw = (cx - 1) * a.step + a.sw, fh = (cy - 1) * a.step + a.sh;
-    const int ss = fw + 1;
+    const int ss = a.ss_row;
 
     uint32_t *sat = lds;
     int32_t *leaf = (int32_t *)(lds + a.ss_max);
     float *p3s = (float *)(leaf + a.px * a.py * T);
     uint32_t *active = (uint32_t *)(p3s + a.px * a.py * 3);
-    uint32_t *misc = active + a.px * a.py;   // [0] n_active, [1] queue head, [2] hit total, [3] hit base
+    uint32_t *misc = active + a.px * a.py;   // [0] n_active, [1] queue head, [2] hit total, [3] hit base, [4] any pixel
 
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
 
-    // ---- phase 1a: row prefix sums.  A wave owns rows wave, wave+16, ...; it first issues the
-    // global loads of ROWS_IN_FLIGHT rows (4 pixels per lane, one 8-byte load when aligned) and only
-    // then scans them, so a tile pays two or three global-memory round trips instead of one per row.
+    // ---- phase 1a: vertical running sums straight from global memory.  Unit = (group of 4
+    // columns, segment of rows); a thread issues the loads of up to ROWS_IN_FLIGHT rows (one 8-byte
+    // load each when aligned) before it touches them: one global round trip per tile, all lanes
+    // busy, no cross-lane traffic.  sat[y+1][x+1] = sum of the column above within the segment.
     if (tid < 8) misc[tid] = 0;
-    for (int i = tid; i < ss; i += TRAV_THREADS) sat[i] = 0;          // row 0
+    for (int i = tid; i <= fw; i += TRAV_THREADS) sat[i] = 0;                     // row 0
+    for (int i = tid; i < fh; i += TRAV_THREADS) sat[(i + 1) * ss] = 0;           // column 0
     const bool al8 = ((a.w & 3) == 0) && ((fx0 & 3) == 0) && ((((size_t)img) & 7) == 0);
-    const int nchunk = (fw + WAVE * 4 - 1) / (WAVE * 4);
+    const int CG = (fw + 3) >> 2;
+    const int SG = max(1, min(16, TRAV_THREADS / CG));
+    const int RV = (fh + SG - 1) / SG;
     uint32_t any_px = 0;
-    for (int r0 = wave; r0 < fh; r0 += TRAV_WAVES * ROWS_IN_FLIGHT) {
-        uint32_t carry[ROWS_IN_FLIGHT];
-#pragma unroll
-        for (int g = 0; g < ROWS_IN_FLIGHT; ++g) carry[g] = 0;
-        for (int c = 0; c < nchunk; ++c) {
-            const int x = c * WAVE * 4 + lane * 4;
+    for (int u = tid; u < CG * SG; u += TRAV_THREADS) {
+        const int x = (u % CG) * 4, sg = u / CG;
+        const int ya = sg * RV, yb = min(fh, ya + RV);
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        for (int y0 = ya; y0 < yb; y0 += ROWS_IN_FLIGHT) {
             uint32_t p[ROWS_IN_FLIGHT][4];
 #pragma unroll
             for (int g = 0; g < ROWS_IN_FLIGHT; ++g) {
-                const int r = r0 + g * TRAV_WAVES;
+                const int y = y0 + g;
                 p[g][0] = p[g][1] = p[g][2] = p[g][3] = 0;
-                if (r < fh) {
-                    const uint16_t *row = img + (size_t)(fy0 + r) * a.w + fx0;
+                if (y < yb) {
+                    const uint16_t *row = img + (size_t)(fy0 + y) * a.w + fx0 + x;
                     if (al8 && x + 3 < fw) {
-                        uint2 q = *(const uint2 *)(row + x);
+                        uint2 q = *(const uint2 *)row;
                         p[g][0] = q.x & 0xffffu; p[g][1] = q.x >> 16; p[g][2] = q.y & 0xffffu; p[g][3] = q.y >> 16;
                     } else {
-                        if (x + 0 < fw) p[g][0] = row[x + 0];
-                        if (x + 1 < fw) p[g][1] = row[x + 1];
-                        if (x + 2 < fw) p[g][2] = row[x + 2];
-                        if (x + 3 < fw) p[g][3] = row[x + 3];
+                        p[g][0] = row[0];
+                        if (x + 1 < fw) p[g][1] = row[1];
+                        if (x + 2 < fw) p[g][2] = row[2];
+                        if (x + 3 < fw) p[g][3] = row[3];
                     }
                 }
             }
 #pragma unroll
             for (int g = 0; g < ROWS_IN_FLIGHT; ++g) {
-                const int r = r0 + g * TRAV_WAVES;
-                if (r >= fh) continue;          // wave-uniform
-                uint32_t *dst = sat + (r + 1) * ss;
-                if (c == 0 && lane == 0) dst[0] = 0;                   // column 0
-                uint32_t s0 = p[g][0], s1 = s0 + p[g][1], s2 = s1 + p[g][2], s3 = s2 + p[g][3];
-                any_px |= s3;
-                uint32_t incl = s3;                                    // wave inclusive scan of lane totals
-#pragma unroll
-                for (int d = 1; d < WAVE; d <<= 1) {
-                    uint32_t o = __shfl_up(incl, d);
-                    if (lane >= d) incl += o;
+                const int y = y0 + g;
+                if (y < yb) {
+                    r0 += p[g][0]; r1 += p[g][1]; r2 += p[g][2]; r3 += p[g][3];
+                    uint32_t *dst = sat + (y + 1) * ss + x + 1;
+                    dst[0] = r0;
+                    if (x + 1 < fw) dst[1] = r1;
+                    if (x + 2 < fw) dst[2] = r2;
+                    if (x + 3 < fw) dst[3] = r3;
                 }
-                uint32_t base = carry[g] + incl - s3;
-                if (x + 0 < fw) dst[x + 1] = base + s0;
-                if (x + 1 < fw) dst[x + 2] = base + s1;
-                if (x + 2 < fw) dst[x + 3] = base + s2;
-                if (x + 3 < fw) dst[x + 4] = base + s3;
-                carry[g] += __shfl(incl, WAVE - 1);
             }
         }
+        any_px |= r0 | r1 | r2 | r3;
     }
     if (__ballot(any_px != 0) != 0ull && lane == 0) misc[4] = 1;
     __syncthreads();
@@ -282,50 +335,74 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             }
         return;
     }
-    // ---- phase 1b: column prefix sums in SEG row segments per column (local scans, then each segment
-    // adds the totals of the segments above it): ~fh/SEG + SEG dependent steps instead of fh
-    {
-        const int seg = max(1, min(8, TRAV_THREADS / fw));
-        const int rows = (fh + seg - 1) / seg;
-        const int units = fw * seg;                      // unit u = (segment u / fw, column 1 + u % fw)
-        for (int u = tid; u < units; u += TRAV_THREADS) {
-            const int sidx = u / fw;
-            uint32_t *col = sat + 1 + u % fw;
-            const int y0 = 1 + sidx * rows, y1 = min(fh, y0 + rows - 1);
-            uint32_t run = 0;
-#pragma unroll 4
-            for (int y = y0; y <= y1; ++y) { run += col[y * ss]; col[y * ss] = run; }
+    if (a.stop_phase == 1) return;
+    // ---- phase 1b: stitch the row segments (each segment adds the totals of the segments above)
+    if (SG > 1) {
+        uint32_t off[4] = {0, 0, 0, 0};                  // fw * SG <= 4096 units -> at most 4 per thread
+        int k = 0;
+        for (int u = tid; u < fw * SG; u += TRAV_THREADS, ++k) {
+            const int sg = u / fw;
+            const uint32_t *col = sat + 1 + u % fw;
+            uint32_t o = 0;
+            for (int s2 = 0; s2 < sg; ++s2) {
+                const int ye = min(fh, (s2 + 1) * RV);
+                if (ye > s2 * RV) o += col[ye * ss];
+            }
+            off[k & 3] = o;
         }
         __syncthreads();
-        uint32_t off[4] = {0, 0, 0, 0};                  // fw <= 4096 -> at most 4 units per thread
-        if (seg > 1) {
+        k = 0;
+        for (int u = tid; u < fw * SG; u += TRAV_THREADS, ++k) {
+            const int sg = u / fw;
+            uint32_t *col = sat + 1 + u % fw;
+            const int ya = sg * RV, yb = min(fh, ya + RV);
+            const uint32_t o = off[k & 3];
+            if (o)
+                for (int y = ya; y < yb; ++y) col[(y + 1) * ss] += o;
+        }
+        __syncthreads();
+    }
+    // ---- phase 1c: horizontal prefix sums inside LDS, unit = (row, segment of columns); lanes
+    // hold different rows and the row stride is odd, so every access is bank-conflict free
+    {
+        const int SH = max(1, min(8, TRAV_THREADS / fh));
+        const int CW = (fw + SH - 1) / SH;
+        for (int u = tid; u < fh * SH; u += TRAV_THREADS) {
+            const int sg = u / fh;
+            uint32_t *row = sat + (1 + u % fh) * ss + 1;
+            const int xa = sg * CW, xb = min(fw, xa + CW);
+            uint32_t run = 0;
+#pragma unroll 4
+            for (int x = xa; x < xb; ++x) { run += row[x]; row[x] = run; }
+        }
+        __syncthreads();
+        if (SH > 1) {
+            uint32_t off[4] = {0, 0, 0, 0};
             int k = 0;
-            for (int u = tid; u < units; u += TRAV_THREADS, ++k) {
-                const int sidx = u / fw;
-                const uint32_t *col = sat + 1 + u % fw;
+            for (int u = tid; u < fh * SH; u += TRAV_THREADS, ++k) {
+                const int sg = u / fh;
+                const uint32_t *row = sat + (1 + u % fh) * ss;
                 uint32_t o = 0;
-                for (int s2 = 0; s2 < sidx; ++s2) {
-                    int ye = min(fh, (s2 + 1) * rows);
-                    if (ye >= 1 + s2 * rows) o += col[ye * ss];
+                for (int s2 = 0; s2 < sg; ++s2) {
+                    const int xe = min(fw, (s2 + 1) * CW);
+                    if (xe > s2 * CW) o += row[xe];
                 }
                 off[k & 3] = o;
             }
-        }
-        __syncthreads();
-        if (seg > 1) {
-            int k = 0;
-            for (int u = tid; u < units; u += TRAV_THREADS, ++k) {
-                const int sidx = u / fw;
-                uint32_t *col = sat + 1 + u % fw;
-                const int y0 = 1 + sidx * rows, y1 = min(fh, y0 + rows - 1);
+            __syncthreads();
+            k = 0;
+            for (int u = tid; u < fh * SH; u += TRAV_THREADS, ++k) {
+                const int sg = u / fh;
+                uint32_t *row = sat + (1 + u % fh) * ss + 1;
+                const int xa = sg * CW, xb = min(fw, xa + CW);
                 const uint32_t o = off[k & 3];
                 if (o)
-#pragma unroll 4
-                    for (int y = y0; y <= y1; ++y) col[y * ss] += o;
+                    for (int x = xa; x < xb; ++x) row[x] += o;
             }
+            __syncthreads();
         }
     }
-    __syncthreads();
+    if (a.stop_phase == 2) return;
 
     // ---- phase 2: per patch: centre -> 3-D (prediction.rs:551-554), background gate (:567-571)
     for (int p = tid; p < npt; p += TRAV_THREADS) {
@@ -348,6 +425,37 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         }
     }
     __syncthreads();
+    if (a.stop_phase == 3) return;
+    const int n_active = (int)misc[0];
+    if (n_active == 0) return;     // nothing to walk, no hits (debug taps were written above)
+
+    // ---- phase 2b (UNI): SAT -> box-sum image, in place.  Slot (y, x) becomes the sum of the
+    // rw x rh rectangle whose top-left is (x, y); it reads slots (y,x) (y,x+rw) (y+rh,x) (y+rh,x+rw),
+    // all at or below/right of the slot it overwrites, so bands of rows are converted top-down:
+    // every thread first computes its cells of the band, then (after a barrier) stores them.
+    if (UNI) {
+        const int bw = fw - a.rw + 1, bh = fh - a.rh + 1;
+        const int BH = max(1, (4 * TRAV_THREADS) / bw);
+        for (int y0 = 0; y0 < bh; y0 += BH) {
+            const int cells = min(BH, bh - y0) * bw;
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = tid + k * TRAV_THREADS;
+                if (c < cells) {
+                    const uint32_t *s0 = sat + (y0 + c / bw) * ss + c % bw;
+                    v[k] = s0[a.rh * ss + a.rw] - s0[a.rw] - s0[a.rh * ss] + s0[0];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = tid + k * TRAV_THREADS;
+                if (c < cells) sat[(y0 + c / bw) * ss + c % bw] = v[k];
+            }
+            __syncthreads();
+        }
+    }
 
     // ---- phase 3: root->leaf walks.  Work item i = (tree i / n_active, active slot i % n_active), so
     // the lanes of a wave start in the same tree and share its top-level nodes.  Lanes whose walk
@@ -355,9 +463,9 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // reserves that many items, each lane takes base + (its rank among the refilling lanes).
     // Every lane leaves the loop once the queue is exhausted and its own walk hit a leaf; trees
     // are validated acyclic on the host, so every walk ends.
-    const int n_active = (int)misc[0];
     const int total = n_active * T;
     {
+        const NodeU *nodes_u = (const NodeU *)a.nodes_u;
         int item = -1;      // -1: needs work, -2: queue exhausted
         int cur = 0, pbase = 0, lslot = 0;
         for (;;) {
@@ -389,25 +497,41 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             }
             if (item >= 0) {
                 // HoughTreeFunctions::binarize (houghforest.rs:185-193) with O(1) rect sums
-                const uint4 *np = (const uint4 *)(a.f.nodes + cur);
-                uint4 n0 = np[0], n1 = np[1];
-                int ax0 = n0.x & 0xffff, ay0 = n0.x >> 16, ax1 = n0.y & 0xffff, ay1 = n0.y >> 16;
-                int bx0 = n0.z & 0xffff, by0 = n0.z >> 16, bx1 = n0.w & 0xffff, by1 = n0.w >> 16;
-                double thr = __hiloint2double((int)n1.y, (int)n1.x);
-                const uint32_t *sp = sat + pbase;
-                uint32_t s1 = sp[ay1 * ss + ax1] - sp[ay0 * ss + ax1] - sp[ay1 * ss + ax0] + sp[ay0 * ss + ax0];
-                uint32_t s2 = sp[by1 * ss + bx1] - sp[by0 * ss + bx1] - sp[by1 * ss + bx0] + sp[by0 * ss + bx0];
-                uint32_t c1 = (uint32_t)((ax1 - ax0) * (ay1 - ay0)), c2 = (uint32_t)((bx1 - bx0) * (by1 - by0));
-                double a1 = c1 ? __ddiv_rn((double)s1, (double)c1) : 0.0;   // types.rs:335-338
-                double a2 = c2 ? __ddiv_rn((double)s2, (double)c2) : 0.0;
-                bool one = __dsub_rn(a1, a2) > thr;
-                cur = one ? (int)n1.w : (int)n1.z;
+                if (UNI) {
+                    const uint4 nd = *(const uint4 *)(nodes_u + cur);
+                    const uint32_t *sp = sat + pbase;
+                    const uint32_t s1 = sp[nd.x & 0x3fffu], s2 = sp[(nd.x >> 14) & 0x3fffu];
+                    const int32_t d = (int32_t)s1 - (int32_t)s2, ilo = (int32_t)nd.y;
+                    bool one = d > ilo;
+                    const uint32_t amb = nd.x >> 28;
+                    if (amb && one && d <= ilo + (int32_t)amb) {
+                        // inside the band the integer test cannot decide: the reference's own arithmetic
+                        const double thr = a.f.nodes[cur].threshold, c = (double)a.area;
+                        one = __dsub_rn(__ddiv_rn((double)s1, c), __ddiv_rn((double)s2, c)) > thr;   // types.rs:338
+                    }
+                    cur = one ? (int)nd.w : (int)nd.z;
+                } else {
+                    const uint4 *np = (const uint4 *)(a.f.nodes + cur);
+                    uint4 n0 = np[0], n1 = np[1];
+                    int ax0 = n0.x & 0xffff, ay0 = n0.x >> 16, ax1 = n0.y & 0xffff, ay1 = n0.y >> 16;
+                    int bx0 = n0.z & 0xffff, by0 = n0.z >> 16, bx1 = n0.w & 0xffff, by1 = n0.w >> 16;
+                    double thr = __hiloint2double((int)n1.y, (int)n1.x);
+                    const uint32_t *sp = sat + pbase;
+                    uint32_t s1 = sp[ay1 * ss + ax1] - sp[ay0 * ss + ax1] - sp[ay1 * ss + ax0] + sp[ay0 * ss + ax0];
+                    uint32_t s2 = sp[by1 * ss + bx1] - sp[by0 * ss + bx1] - sp[by1 * ss + bx0] + sp[by0 * ss + bx0];
+                    uint32_t c1 = (uint32_t)((ax1 - ax0) * (ay1 - ay0)), c2 = (uint32_t)((bx1 - bx0) * (by1 - by0));
+                    double a1 = c1 ? __ddiv_rn((double)s1, (double)c1) : 0.0;   // types.rs:335-338
+                    double a2 = c2 ? __ddiv_rn((double)s2, (double)c2) : 0.0;
+                    bool one = __dsub_rn(a1, a2) > thr;
+                    cur = one ? (int)n1.w : (int)n1.z;
+                }
                 if (cur < 0) { leaf[lslot] = ~cur; item = -1; }
             }
         }
     }
     __syncthreads();
 
+    if (a.stop_phase == 4) return;
     // ---- phase 4: mean leaf probability in tree order (prediction.rs:582-584), hit records
     uint32_t my_hits = 0, my_base = 0;
     int my_p = -1;
@@ -434,7 +558,8 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         }
     }
     __syncthreads();
-    if (tid == 0 && misc[2]) misc[3] = atomicAdd(&a.hit_count[frame], misc[2]);
+    if (misc[2] == 0) return;
+    if (tid == 0) misc[3] = atomicAdd(&a.hit_count[frame], misc[2]);
     __syncthreads();
     if (my_hits) {
         uint32_t o = misc[3] + my_base;
@@ -469,14 +594,16 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
 hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_traverse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)k_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     int frames8 = (a.n_frames + 7) / 8 * 8;
     int grid = frames8 * a.tiles_x * a.tiles_y;
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_traverse, dim3(grid), dim3(TRAV_THREADS), lds_bytes, s, a);
+    if (a.uniform) hipLaunchKernelGGL(k_traverse<true>, dim3(grid), dim3(TRAV_THREADS), lds_bytes, s, a);
+    else hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(TRAV_THREADS), lds_bytes, s, a);
     return hipGetLastError();
 }
 

@@ -103,7 +103,7 @@ def biwi_batch(n: int, w: int = 640, h: int = 480, first: int = 0) -> np.ndarray
 
 def synth_forest(n_trees: int = 10, max_depth: int = 15, seed: int = FOREST_SEED_BASE,
                  patch: tuple[int, int] = (80, 80), rect_scale: float = 0.3,
-                 full_depth: int = 6, p_split: float = 0.75) -> Forest:
+                 full_depth: int = 6, p_split: float = 0.75, rect_scale_max: float | None = None) -> Forest:
     """Random forest with the trainer's geometry.
 
     Structure: nodes shallower than `full_depth` always split, deeper ones split with probability
@@ -160,9 +160,14 @@ def synth_forest(n_trees: int = 10, max_depth: int = 15, seed: int = FOREST_SEED
         nodes["child_zero"] = cz.astype(np.int32)
         nodes["child_one"] = co.astype(np.int32)
         for key in ("r1", "r2"):
-            x0 = rng.randint(0, pw - rw - 1, n_nodes)
-            y0 = rng.randint(0, ph - rh - 1, n_nodes)
-            nodes[key] = np.stack([x0, y0, x0 + rw, y0 + rh], axis=1).astype(np.uint16)
+            if rect_scale_max is None:      # the trainer's geometry: one rectangle size for the whole forest
+                w_, h_ = np.full(n_nodes, rw), np.full(n_nodes, rh)
+            else:                           # mixed sizes (general path): scale drawn per rectangle
+                sc = rect_scale + (rect_scale_max - rect_scale) * rng.uniform(n_nodes)
+                w_, h_ = np.maximum((pw * sc).astype(np.int64), 1), np.maximum((ph * sc).astype(np.int64), 1)
+            x0 = (rng.uniform(n_nodes) * (pw - w_)).astype(np.int64)     # Rect::scale_and_replace, types.rs:82-91
+            y0 = (rng.uniform(n_nodes) * (ph - h_)).astype(np.int64)
+            nodes[key] = np.stack([x0, y0, x0 + w_, y0 + h_], axis=1).astype(np.uint16)
         nodes["threshold"] = rng.uniform(n_nodes) * 512.0 - 256.0
         if n_nodes:
             cx0, cy0 = (pw - rw) // 2, (ph - rh) // 2

@@ -60,17 +60,71 @@ def _check_frames(hp_mod, oracle, forest, model, frames, K, midp=None, rot=None,
     return poses
 
 
+class general_path:
+    """Force the general (SAT + f64 division) traversal instead of the uniform-rectangle fast path."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        import os
+        if self.on:
+            os.environ["DH_FORCE_GENERAL"] = "1"
+
+    def __exit__(self, *exc):
+        import os
+        os.environ.pop("DH_FORCE_GENERAL", None)
+
+
+@pytest.mark.parametrize("general", [False, True])
 @pytest.mark.parametrize("w,h,step,trees,depth", [
     (160, 120, 4, 5, 8),
     (200, 152, 3, 10, 12),
     (320, 240, 1, 3, 6),     # BASELINE config 5 geometry, small forest
     (320, 240, 7, 10, 15),
 ])
-def test_stagewise_small(hp_mod, oracle, w, h, step, trees, depth):
+def test_stagewise_small(hp_mod, oracle, w, h, step, trees, depth, general):
     forest = synth.synth_forest(trees, depth, synth.FOREST_SEED_BASE + 100 + step)
-    model = synth.ModelParams(stepwidth=step)
-    frames = synth.biwi_batch(3, w, h, first=10)
-    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h))
+    with general_path(general):
+        model = synth.ModelParams(stepwidth=step)
+        frames = synth.biwi_batch(3, w, h, first=10)
+        _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h))
+
+
+def test_mixed_rectangle_sizes(hp_mod, oracle):
+    """Rectangles of different sizes in one forest (c1 != c2): the general traversal."""
+    forest = synth.synth_forest(8, 11, synth.FOREST_SEED_BASE + 150, rect_scale=0.1, rect_scale_max=0.6)
+    sizes = {(int(r[2] - r[0]), int(r[3] - r[1])) for r in forest.nodes["r1"][:50]}
+    assert len(sizes) > 5
+    model = synth.ModelParams(stepwidth=4)
+    frames = synth.biwi_batch(3, 320, 240, first=15)
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(320, 240))
+
+
+def test_integer_threshold_edge_cases(hp_mod, oracle):
+    """Thresholds that sit exactly on, or within one ulp of, a representable box-sum difference:
+    the integer test must hand those to the exact f64 path (k_nodes_compact's ambiguity band)."""
+    forest = synth.synth_forest(6, 9, synth.FOREST_SEED_BASE + 151)
+    c = 24.0 * 24.0
+    thr = forest.nodes["threshold"]
+    k = np.round(thr * c)
+    exact = k / c                                   # delta == thr is reachable: d > thr must be false there
+    sel = np.arange(thr.size) % 4
+    thr[sel == 0] = exact[sel == 0]
+    thr[sel == 1] = np.nextafter(exact[sel == 1], np.inf)
+    thr[sel == 2] = np.nextafter(exact[sel == 2], -np.inf)
+    thr[sel == 3] = np.where(np.arange(thr.size)[sel == 3] % 8 == 3, 0.0, thr[sel == 3])
+    thr[5] = 1e9; thr[6] = -1e9; thr[7] = 65535.0; thr[8] = -65535.0; thr[9] = np.inf; thr[10] = -np.inf
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 240, 200
+    frames = synth.biwi_batch(3, w, h, first=33)
+    frames[1] = (frames[1] > 0) * 800               # flat foreground: many exactly-equal box sums (delta == 0)
+    frames[2] = np.where(frames[2] > 0, 65535, 0)   # saturated: largest possible sums
+    _check_frames(hp_mod, oracle, forest, model, frames.astype(np.uint16), synth.default_intrinsic(w, h))
+    with general_path(True):
+        _check_frames(hp_mod, oracle, forest, model, frames.astype(np.uint16), synth.default_intrinsic(w, h))
+
+
 
 
 def test_config1_single_frame_stride10(hp_mod, oracle):
