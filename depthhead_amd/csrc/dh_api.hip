@@ -351,6 +351,7 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     STEP(dev_alloc(p, &d.off_max, (size_t)p->n_leaves * 3, true));
     STEP(dev_alloc(p, &d.rbin_box, p->n_leaves, true));
     STEP(dev_alloc(p, &d.rbin_box_hi, p->n_leaves, true));
+    STEP(dev_alloc(p, &d.tpl, p->n_leaves, true));
     STEP(dev_alloc(p, &p->kern_ord, DH_GRID3));
     { uint4 *nu = nullptr; STEP(dev_alloc(p, &nu, p->n_nodes, true)); p->nodes_u = nu; }
 #undef STEP

@@ -16,6 +16,17 @@
 #define LF_ROT 2u    // trace(cov(rotations)) <= 400.0  (prediction.rs:600)
 #define LF_OFF 4u    // trace(cov(offsets))  <= 5200.0  (prediction.rs:643)
 
+// Everything k_traverse needs to turn (patch, leaf) into its three hit records: 4 x 16-byte loads.
+struct __attribute__((aligned(16))) LeafTpl {
+    float    omin[3], omax[3];   // offset bounding box (off_min / off_max)
+    uint32_t v;                  // valtoadd
+    uint32_t fc;                 // LF_* | n_offsets << 8
+    uint32_t ob;                 // first offset vote
+    uint32_t rlo, rhi;           // rotation-bin bounding box (rlo = 0xFFFFFFFF: no rotation votes)
+    uint32_t rb, n_rot;          // rotation votes
+    uint32_t pad[3];
+};
+
 // Device view of a forest: the flat arrays of dh_forest_desc plus the per-leaf tables that depend
 // only on the leaf (last note) and are computed once by k_leaf_prepare.
 struct DevForest {
@@ -36,6 +47,7 @@ struct DevForest {
     float    *off_max;     // per leaf, 3 floats                                     (+inf if non-finite)
     uint32_t *rbin_box;    // per leaf: component-wise minimum of its rotation bins, r1 | r2<<8 | r3<<16
     uint32_t *rbin_box_hi; // per leaf: component-wise maximum, same packing
+    struct LeafTpl *tpl;   // per leaf: everything a hit record needs, one 64-byte line
 };
 
 // One (gated patch, voting leaf) pair = three self-contained 16/32-byte records, so that neither the

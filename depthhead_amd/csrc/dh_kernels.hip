@@ -160,6 +160,12 @@ __global__ void __launch_bounds__(256) k_leaf_prepare(DevForest f) {
     for (int k = 0; k < 3; ++k) { f.off_min[L * 3 + k] = omin[k]; f.off_max[L * 3 + k] = omax[k]; }
     f.rbin_box[L] = bmin[0] | (bmin[1] << 8) | (bmin[2] << 16);
     f.rbin_box_hi[L] = bmax[0] | (bmax[1] << 8) | (bmax[2] << 16);
+    LeafTpl t;
+    for (int k = 0; k < 3; ++k) { t.omin[k] = omin[k]; t.omax[k] = omax[k]; }
+    t.v = v; t.fc = flags | (n_off << 8); t.ob = ob;
+    t.rlo = (flags & LF_ROT) ? f.rbin_box[L] : 0xFFFFFFFFu; t.rhi = f.rbin_box_hi[L];
+    t.rb = rb; t.n_rot = n_rot; t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    f.tpl[L] = t;
 }
 
 hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s) {
@@ -240,7 +246,7 @@ size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_tre
     size_t fw = (size_t)(px - 1) * step + sw, fh = (size_t)(py - 1) * step + sh;
     size_t ss = (fw + 1) | 1;      // odd row stride: row-per-lane LDS passes are bank-conflict free
     size_t npt = (size_t)px * py;
-    return (ss * (fh + 1) + npt * n_trees + npt * 3 + npt + 16) * 4;   // keep in step with the carve-up in k_traverse
+    return (ss * (fh + 1) + npt * n_trees + npt * 3 + npt * 2 + 16) * 4;   // keep in step with the carve-up in k_traverse
 }
 
 template <bool UNI>
@@ -255,7 +261,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
     const int frame = (j / tiles) * 8 + xcd;
     const int tile = j % tiles;
-    if (frame >= a.n_frames) return;
+    if (frame >= a.n_frames || a.stop_phase == 9) return;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int cx = min(a.px, a.nx - tx * a.px), cy = min(a.py, a.ny - ty * a.py);
     const int npt = cx * cy;
@@ -267,7 +273,8 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     int32_t *leaf = (int32_t *)(lds + a.ss_max);
     float *p3s = (float *)(leaf + a.px * a.py * T);
     uint32_t *active = (uint32_t *)(p3s + a.px * a.py * 3);
-    uint32_t *misc = active + a.px * a.py;   // [0] n_active, [1] queue head, [2] hit total, [3] hit base, [4] any pixel
+    uint32_t *pres = active + a.px * a.py;   // per active slot: hit base | gated << 31
+    uint32_t *misc = pres + a.px * a.py;     // [0] n_active, [1] queue head, [2] hit total, [3] hit base, [4] any pixel
 
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
 
@@ -435,12 +442,12 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // every thread first computes its cells of the band, then (after a barrier) stores them.
     if (UNI) {
         const int bw = fw - a.rw + 1, bh = fh - a.rh + 1;
-        const int BH = max(1, (4 * TRAV_THREADS) / bw);
+        const int BH = max(1, (6 * TRAV_THREADS) / bw);
         for (int y0 = 0; y0 < bh; y0 += BH) {
             const int cells = min(BH, bh - y0) * bw;
-            uint32_t v[4];
+            uint32_t v[6];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 6; ++k) {
                 const int c = tid + k * TRAV_THREADS;
                 if (c < cells) {
                     const uint32_t *s0 = sat + (y0 + c / bw) * ss + c % bw;
@@ -449,7 +456,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             }
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 6; ++k) {
                 const int c = tid + k * TRAV_THREADS;
                 if (c < cells) sat[(y0 + c / bw) * ss + c % bw] = v[k];
             }
@@ -532,7 +539,75 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     __syncthreads();
 
     if (a.stop_phase == 4) return;
-    // ---- phase 4: mean leaf probability in tree order (prediction.rs:582-584), hit records
+    // ---- phase 4: mean leaf probability in tree order (prediction.rs:582-584), hit records.
+    // The SAT / box image is dead now; its LDS is reused as scratch for the (patch, tree) pairs so
+    // that every dependent global load of this phase is issued by a different thread.
+    const int pairs = n_active * T;
+    double *sprob = (double *)sat;                       // [pairs]
+    uint32_t *sflag = (uint32_t *)(sprob + pairs);       // [pairs]
+    const bool fits = (size_t)pairs * 12 <= (size_t)a.ss_max * 4;
+    if (fits) {
+        for (int i = tid; i < pairs; i += TRAV_THREADS) {
+            const int slot = i / T, t = i - slot * T;
+            const uint32_t lid = (uint32_t)leaf[(int)active[slot] * T + t];
+            sprob[i] = a.f.leaf_prob[lid];
+            sflag[i] = a.f.leaf_flags[lid];
+        }
+        __syncthreads();
+        if (tid < n_active) {
+            double prob = 0.0;
+            for (int t = 0; t < T; ++t) prob = __dadd_rn(prob, sprob[tid * T + t]);     // tree order, f64
+            prob = __ddiv_rn(prob, (double)T);
+            const bool gated = prob > DH_PROB_GATE;
+            uint32_t cnt = 0;
+            if (gated)
+                for (int t = 0; t < T; ++t) {
+                    const uint32_t lf = sflag[tid * T + t];
+                    if ((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF))) cnt++;
+                }
+            pres[tid] = (cnt ? atomicAdd(&misc[2], cnt) : 0u) | (gated ? 0x80000000u : 0u);
+            if (a.dbg_flags) {
+                const int p = (int)active[tid], pxi = p % cx, pyi = p / cx;
+                const int gp = (ty * a.py + pyi) * a.nx + tx * a.px + pxi;
+                const size_t o = (size_t)frame * a.nx * a.ny + gp;
+                if (gated) a.dbg_flags[o] = 3;
+                if (a.dbg_leaf)
+                    for (int t = 0; t < T; ++t) a.dbg_leaf[o * T + t] = leaf[p * T + t];
+            }
+        }
+        __syncthreads();
+        if (misc[2] == 0) return;
+        if (tid == 0) misc[3] = atomicAdd(&a.hit_count[frame], misc[2]);
+        __syncthreads();
+        HitRec *dst = a.hits + (size_t)frame * a.hits_cap;
+        HitBox *dbox = a.hit_box + (size_t)frame * a.hits_cap;
+        HitRot *drot = a.hit_rot + (size_t)frame * a.hits_cap;
+        for (int i = tid; i < pairs; i += TRAV_THREADS) {
+            const int slot = i / T, t = i - slot * T;
+            const uint32_t pr = pres[slot], lf = sflag[i];
+            if (!(pr & 0x80000000u) || !((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF)))) continue;
+            uint32_t o = misc[3] + (pr & 0x7fffffffu);
+            for (int t2 = 0; t2 < t; ++t2) {                 // rank among this patch's voting leaves
+                const uint32_t l2 = sflag[slot * T + t2];
+                o += ((l2 & LF_PROB) && (l2 & (LF_ROT | LF_OFF))) ? 1u : 0u;
+            }
+            if (o >= a.hits_cap) continue;
+            const int p = (int)active[slot];
+            const uint32_t lid = (uint32_t)leaf[p * T + t];
+            const uint4 *tp = (const uint4 *)(a.f.tpl + lid);
+            const uint4 t0 = tp[0], t1 = tp[1], t2v = tp[2], t3 = tp[3];
+            const float q0 = p3s[p * 3 + 0], q1 = p3s[p * 3 + 1], q2 = p3s[p * 3 + 2];
+            const float mn0 = __uint_as_float(t0.x), mn1 = __uint_as_float(t0.y), mn2 = __uint_as_float(t0.z),
+                        mx0 = __uint_as_float(t0.w), mx1 = __uint_as_float(t1.x), mx2 = __uint_as_float(t1.y);
+            *(float4 *)(dst + o) = make_float4(q0, q1, q2, __uint_as_float(t2v.x));              // p3, ob
+            ((int4 *)(dbox + o))[0] = make_int4(f32_as_i32(__fsub_rn(q0, mx0)), f32_as_i32(__fsub_rn(q1, mx1)),
+                                                 f32_as_i32(__fsub_rn(q2, mx2)), f32_as_i32(__fsub_rn(q0, mn0)));
+            ((int4 *)(dbox + o))[1] = make_int4(f32_as_i32(__fsub_rn(q1, mn1)), f32_as_i32(__fsub_rn(q2, mn2)), (int)t1.z, (int)t1.w);
+            *(uint4 *)(drot + o) = make_uint4(t2v.y, t2v.z, t2v.w, t3.x);                           // rlo, rhi, rb, n_rot
+        }
+        return;
+    }
+    // ---- fallback for forests too large for the scratch (n_active * T * 12 bytes > SAT): one thread per patch
     uint32_t my_hits = 0, my_base = 0;
     int my_p = -1;
     bool gated = false;
@@ -569,21 +644,14 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         float q0 = p3s[my_p * 3 + 0], q1 = p3s[my_p * 3 + 1], q2 = p3s[my_p * 3 + 2];
         for (int t = 0; t < T; ++t) {
             uint32_t lid = (uint32_t)leaf[my_p * T + t];
-            uint32_t lf = a.f.leaf_flags[lid];
-            if ((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF))) {
+            const LeafTpl tp = a.f.tpl[lid];
+            if ((tp.fc & LF_PROB) && (tp.fc & (LF_ROT | LF_OFF))) {
                 if (o < a.hits_cap) {
-                    const float *mn = a.f.off_min + (size_t)lid * 3, *mx = a.f.off_max + (size_t)lid * 3;
-                    const uint32_t v = a.f.leaf_v[lid];
-                    const uint32_t ob = a.f.off_begin[lid], n_off = a.f.off_begin[lid + 1] - ob;
-                    const uint32_t rb = a.f.rot_begin[lid], n_rot = a.f.rot_begin[lid + 1] - rb;
-                    *(float4 *)(dst + o) = make_float4(q0, q1, q2, __uint_as_float(ob));
-                    int4 b0 = make_int4(f32_as_i32(__fsub_rn(q0, mx[0])), f32_as_i32(__fsub_rn(q1, mx[1])),
-                                        f32_as_i32(__fsub_rn(q2, mx[2])), f32_as_i32(__fsub_rn(q0, mn[0])));
-                    int4 b1 = make_int4(f32_as_i32(__fsub_rn(q1, mn[1])), f32_as_i32(__fsub_rn(q2, mn[2])), (int)v,
-                                        (int)(lf | (n_off << 8)));
-                    ((int4 *)(dbox + o))[0] = b0;
-                    ((int4 *)(dbox + o))[1] = b1;
-                    *(uint4 *)(drot + o) = make_uint4((lf & LF_ROT) ? a.f.rbin_box[lid] : 0xFFFFFFFFu, a.f.rbin_box_hi[lid], rb, n_rot);
+                    *(float4 *)(dst + o) = make_float4(q0, q1, q2, __uint_as_float(tp.ob));
+                    ((int4 *)(dbox + o))[0] = make_int4(f32_as_i32(__fsub_rn(q0, tp.omax[0])), f32_as_i32(__fsub_rn(q1, tp.omax[1])),
+                                                         f32_as_i32(__fsub_rn(q2, tp.omax[2])), f32_as_i32(__fsub_rn(q0, tp.omin[0])));
+                    ((int4 *)(dbox + o))[1] = make_int4(f32_as_i32(__fsub_rn(q1, tp.omin[1])), f32_as_i32(__fsub_rn(q2, tp.omin[2])), (int)tp.v, (int)tp.fc);
+                    *(uint4 *)(drot + o) = make_uint4(tp.rlo, tp.rhi, tp.rb, tp.n_rot);
                 }
                 o++;
             }

@@ -349,3 +349,12 @@ def test_hand_verified_case(hp_mod):
     with hp_mod.HoughPrediction(forest, model, device=0) as hp:
         r = hp.predict_parameter_parallel(img, hp_mod.IntrinsicMatrix(K))
     hc.check(r.mid_point, r.rotation)
+
+
+def test_many_trees_scratch_fallback(hp_mod, oracle):
+    """64 shallow trees: the (patch, tree) scratch of k_traverse's last phase no longer fits the
+    freed SAT, so the per-patch fallback runs."""
+    forest = synth.synth_forest(64, 4, synth.FOREST_SEED_BASE + 160, full_depth=3)
+    model = synth.ModelParams(stepwidth=4)
+    frames = synth.biwi_batch(2, 240, 200, first=70)
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(240, 200), full=False)
