@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--depth", type=int, default=15)
     ap.add_argument("--stride", type=int, default=4)
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames generated per rank (tiled to --frames)")
+    ap.add_argument("--forest", choices=["fitted", "random"], default="fitted",
+                    help="fitted: trainer-sized forest fitted to synthetic subjects (coherent votes, the stand-in for the "
+                         "unavailable pretrained forest); random: 13x larger random-split stress forest")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
     return ap.parse_args()
@@ -77,7 +80,10 @@ def main():
     from depthhead_amd.prediction import HoughPrediction, IntrinsicMatrix
 
     W, H, NF = args.width, args.height, args.frames
-    forest = synth.synth_forest(args.trees, args.depth, synth.FOREST_SEED_BASE + 2)
+    if args.forest == "fitted":
+        forest = synth.fit_forest(args.trees, args.depth, synth.FOREST_SEED_BASE + 2)
+    else:
+        forest = synth.synth_forest(args.trees, args.depth, synth.FOREST_SEED_BASE + 2)
     model = synth.ModelParams(stepwidth=args.stride)
     K = synth.default_intrinsic(W, H)
     intr = IntrinsicMatrix(K)
@@ -150,7 +156,8 @@ def main():
             "dtype": "u32/f64",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {NF} synthetic {W}x{H} u16 depth frames per GPU, "
-                                   f"{args.trees}-tree depth-{args.depth} synthetic forest, stride-{args.stride} "
+                                   f"{args.trees}-tree depth-{args.depth} {args.forest} synthetic forest "
+                                   f"({forest.n_nodes} nodes, {forest.n_leaves} leaves), stride-{args.stride} "
                                    f"80x80 patches, 20 mean-shift iterations",
                        "frames_per_gpu": NF, "width": W, "height": H, "trees": args.trees, "max_depth": args.depth,
                        "stride": args.stride, "parallelism": f"frame-sharded x{world}, RCCL all-gather of poses"},

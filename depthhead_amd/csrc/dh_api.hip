@@ -509,6 +509,18 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
         ta.uniform = g.uniform ? 1 : 0; ta.rw = p->f_rw; ta.rh = p->f_rh; ta.area = (uint32_t)(p->f_rw * p->f_rh);
         ta.nodes_u = p->nodes_u;
         if (const char *e = getenv("DH_TRAV_STOP")) ta.stop_phase = atoi(e);
+        static unsigned long long *stamps = nullptr;
+        if (getenv("DH_TRAV_STAMPS")) {
+            if (!stamps) { HIP_TRY(hipMalloc((void **)&stamps, 64)); HIP_TRY(hipMemset(stamps, 0, 64)); }
+            else {
+                unsigned long long hst[8];
+                HIP_TRY(hipMemcpy(hst, stamps, 64, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[k_traverse cycles/phase summed over workgroups] A=%llu stitchV=%llu horiz=%llu gate=%llu box=%llu walk=%llu tail=%llu\n",
+                        hst[0], hst[1], hst[2], hst[3], hst[4], hst[5], hst[6]);
+                HIP_TRY(hipMemset(stamps, 0, 64));
+            }
+            ta.dbg_stamps = stamps;
+        }
         memcpy(ta.kinv, kinv, sizeof kinv);
         ta.f = p->dev;
         ta.hits = p->hits; ta.hit_box = p->hit_box; ta.hit_rot = p->hit_rot; ta.hit_count = hit_count; ta.hits_cap = p->hits_cap;

@@ -87,6 +87,7 @@ struct TraverseArgs {
     int rw, rh;
     uint32_t area;          // rw * rh
     const void *nodes_u;    // NodeU[n_nodes], built by k_nodes_compact for this ss_row
+    unsigned long long *dbg_stamps; // profiling: [8] summed cycles per phase over all workgroups (env DH_TRAV_STAMPS)
     int stop_phase;         // profiling knob (env DH_TRAV_STOP): 0 = run everything, k = return after phase k
     float kinv[9];
     DevForest f;

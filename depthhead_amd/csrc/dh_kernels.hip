@@ -249,6 +249,13 @@ size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_tre
     return (ss * (fh + 1) + npt * n_trees + npt * 3 + npt * 2 + 16) * 4;   // keep in step with the carve-up in k_traverse
 }
 
+#define STAMP(k)                                                                        \
+    if (a.dbg_stamps && tid == 0) {                                                     \
+        unsigned long long t_ = clock64();                                              \
+        atomicAdd(&a.dbg_stamps[k], t_ - t_prev);                                        \
+        t_prev = t_;                                                                    \
+    }
+
 template <bool UNI>
 __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -277,6 +284,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     uint32_t *misc = pres + a.px * a.py;     // [0] n_active, [1] queue head, [2] hit total, [3] hit base, [4] any pixel
 
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
+    unsigned long long t_prev = a.dbg_stamps ? clock64() : 0ull;
 
     // ---- phase 1a: vertical running sums straight from global memory.  Unit = (group of 4
     // columns, segment of rows); a thread issues the loads of up to ROWS_IN_FLIGHT rows (one 8-byte
@@ -291,7 +299,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     const int RV = (fh + SG - 1) / SG;
     uint32_t any_px = 0;
     for (int u = tid; u < CG * SG; u += TRAV_THREADS) {
-        const int x = (u % CG) * 4, sg = u / CG;
+        const int sg = u / CG, x = (u - sg * CG) * 4;
         const int ya = sg * RV, yb = min(fh, ya + RV);
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         for (int y0 = ya; y0 < yb; y0 += ROWS_IN_FLIGHT) {
@@ -343,73 +351,82 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         return;
     }
     if (a.stop_phase == 1) return;
-    // ---- phase 1b: stitch the row segments (each segment adds the totals of the segments above)
+    STAMP(0)
+    // ---- phase 1b: stitch the row segments.  First the last row of every segment is made final by
+    // one thread per column (a running sum over at most 16 segment totals, loads issued up front),
+    // then every other row adds the final value of the segment above it: one read per unit.
     if (SG > 1) {
-        uint32_t off[4] = {0, 0, 0, 0};                  // fw * SG <= 4096 units -> at most 4 per thread
-        int k = 0;
-        for (int u = tid; u < fw * SG; u += TRAV_THREADS, ++k) {
-            const int sg = u / fw;
-            const uint32_t *col = sat + 1 + u % fw;
-            uint32_t o = 0;
-            for (int s2 = 0; s2 < sg; ++s2) {
-                const int ye = min(fh, (s2 + 1) * RV);
-                if (ye > s2 * RV) o += col[ye * ss];
-            }
-            off[k & 3] = o;
+        for (int x = tid; x < fw; x += TRAV_THREADS) {
+            uint32_t *col = sat + 1 + x;
+            uint32_t tot[16];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) tot[s2] = s2 < SG ? col[min(fh, (s2 + 1) * RV) * ss] : 0u;
+            uint32_t run = tot[0];
+#pragma unroll
+            for (int s2 = 1; s2 < 16; ++s2)
+                if (s2 < SG && s2 * RV < fh) { run += tot[s2]; col[min(fh, (s2 + 1) * RV) * ss] = run; }
         }
         __syncthreads();
-        k = 0;
-        for (int u = tid; u < fw * SG; u += TRAV_THREADS, ++k) {
-            const int sg = u / fw;
-            uint32_t *col = sat + 1 + u % fw;
-            const int ya = sg * RV, yb = min(fh, ya + RV);
-            const uint32_t o = off[k & 3];
-            if (o)
-                for (int y = ya; y < yb; ++y) col[(y + 1) * ss] += o;
+        {
+            const int q = TRAV_THREADS / fw, r = TRAV_THREADS - q * fw;
+            int sg = tid / fw, x = tid - sg * fw;
+            for (; sg < SG; sg += q, x += r) {
+                if (x >= fw) { x -= fw; ++sg; if (sg >= SG) break; }
+                const int ya = sg * RV, yb = min(fh, ya + RV);          // pixel rows [ya, yb) = SAT rows ya+1 .. yb
+                if (sg == 0 || ya >= fh) continue;
+                uint32_t *col = sat + 1 + x;
+                const uint32_t o = col[ya * ss];                           // final last row of the segment above
+                for (int y = ya + 1; y < yb; ++y) col[y * ss] += o;       // all rows but the (already final) last
+            }
         }
         __syncthreads();
     }
+    STAMP(1)
     // ---- phase 1c: horizontal prefix sums inside LDS, unit = (row, segment of columns); lanes
-    // hold different rows and the row stride is odd, so every access is bank-conflict free
+    // hold different rows and the row stride is odd, so every access is bank-conflict free.
+    // Segment-last columns are stitched like the rows above.
     {
         const int SH = max(1, min(8, TRAV_THREADS / fh));
         const int CW = (fw + SH - 1) / SH;
-        for (int u = tid; u < fh * SH; u += TRAV_THREADS) {
-            const int sg = u / fh;
-            uint32_t *row = sat + (1 + u % fh) * ss + 1;
-            const int xa = sg * CW, xb = min(fw, xa + CW);
-            uint32_t run = 0;
+        const int q = TRAV_THREADS / fh, r = TRAV_THREADS - q * fh;
+        {
+            int sg = tid / fh, y = tid - sg * fh;
+            for (; sg < SH; sg += q, y += r) {
+                if (y >= fh) { y -= fh; ++sg; if (sg >= SH) break; }
+                uint32_t *row = sat + (1 + y) * ss + 1;
+                const int xa = sg * CW, xb = min(fw, xa + CW);
+                uint32_t run = 0;
 #pragma unroll 4
-            for (int x = xa; x < xb; ++x) { run += row[x]; row[x] = run; }
+                for (int x = xa; x < xb; ++x) { run += row[x]; row[x] = run; }
+            }
         }
         __syncthreads();
         if (SH > 1) {
-            uint32_t off[4] = {0, 0, 0, 0};
-            int k = 0;
-            for (int u = tid; u < fh * SH; u += TRAV_THREADS, ++k) {
-                const int sg = u / fh;
-                const uint32_t *row = sat + (1 + u % fh) * ss;
-                uint32_t o = 0;
-                for (int s2 = 0; s2 < sg; ++s2) {
-                    const int xe = min(fw, (s2 + 1) * CW);
-                    if (xe > s2 * CW) o += row[xe];
-                }
-                off[k & 3] = o;
+            for (int y = tid; y < fh; y += TRAV_THREADS) {
+                uint32_t *row = sat + (1 + y) * ss;
+                uint32_t tot[8];
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) tot[s2] = s2 < SH ? row[min(fw, (s2 + 1) * CW)] : 0u;
+                uint32_t run = tot[0];
+#pragma unroll
+                for (int s2 = 1; s2 < 8; ++s2)
+                    if (s2 < SH && s2 * CW < fw) { run += tot[s2]; row[min(fw, (s2 + 1) * CW)] = run; }
             }
             __syncthreads();
-            k = 0;
-            for (int u = tid; u < fh * SH; u += TRAV_THREADS, ++k) {
-                const int sg = u / fh;
-                uint32_t *row = sat + (1 + u % fh) * ss + 1;
-                const int xa = sg * CW, xb = min(fw, xa + CW);
-                const uint32_t o = off[k & 3];
-                if (o)
-                    for (int x = xa; x < xb; ++x) row[x] += o;
+            int sg = tid / fh, y = tid - sg * fh;
+            for (; sg < SH; sg += q, y += r) {
+                if (y >= fh) { y -= fh; ++sg; if (sg >= SH) break; }
+                const int xa = sg * CW, xb = min(fw, xa + CW);           // pixel columns [xa, xb) = SAT columns xa+1 .. xb
+                if (sg == 0 || xa >= fw) continue;
+                uint32_t *row = sat + (1 + y) * ss;
+                const uint32_t o = row[xa];
+                for (int x = xa + 1; x < xb; ++x) row[x] += o;
             }
             __syncthreads();
         }
     }
     if (a.stop_phase == 2) return;
+    STAMP(2)
 
     // ---- phase 2: per patch: centre -> 3-D (prediction.rs:551-554), background gate (:567-571)
     for (int p = tid; p < npt; p += TRAV_THREADS) {
@@ -433,6 +450,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     }
     __syncthreads();
     if (a.stop_phase == 3) return;
+    STAMP(3)
     const int n_active = (int)misc[0];
     if (n_active == 0) return;     // nothing to walk, no hits (debug taps were written above)
 
@@ -443,70 +461,77 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     if (UNI) {
         const int bw = fw - a.rw + 1, bh = fh - a.rh + 1;
         const int BH = max(1, (6 * TRAV_THREADS) / bw);
+        const int q = TRAV_THREADS / bw, r = TRAV_THREADS - q * bw;
+        const int ty0 = tid / bw, tx0 = tid - ty0 * bw;
+        const int jump = a.rh * ss;
         for (int y0 = 0; y0 < bh; y0 += BH) {
-            const int cells = min(BH, bh - y0) * bw;
+            const int rows = min(BH, bh - y0);
             uint32_t v[6];
+            int yy = ty0, xx = tx0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const int c = tid + k * TRAV_THREADS;
-                if (c < cells) {
-                    const uint32_t *s0 = sat + (y0 + c / bw) * ss + c % bw;
-                    v[k] = s0[a.rh * ss + a.rw] - s0[a.rw] - s0[a.rh * ss] + s0[0];
+                if (yy < rows) {
+                    const uint32_t *s0 = sat + (y0 + yy) * ss + xx;
+                    v[k] = s0[jump + a.rw] - s0[a.rw] - s0[jump] + s0[0];
                 }
+                yy += q; xx += r;
+                if (xx >= bw) { xx -= bw; ++yy; }
             }
             __syncthreads();
+            yy = ty0; xx = tx0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const int c = tid + k * TRAV_THREADS;
-                if (c < cells) sat[(y0 + c / bw) * ss + c % bw] = v[k];
+                if (yy < rows) sat[(y0 + yy) * ss + xx] = v[k];
+                yy += q; xx += r;
+                if (xx >= bw) { xx -= bw; ++yy; }
             }
             __syncthreads();
         }
     }
+    // ---- (UNI) node cache: the box image uses rows [0, bh); the rh rows below it are free.  They
+    // take the first NC nodes of every tree (breadth-first order: its top levels), so the first
+    // levels of each walk read 16 bytes from LDS instead of chasing global memory.
+    int NC = 0;
+    const uint4 *ncache = nullptr;
+    if (UNI) {
+        const int st = ((fh + 1 - a.rh) * ss + 3) & ~3;              // first free word, 16-byte aligned
+        NC = min(((fh + 1) * ss - st) / (4 * T), 127);              // 4 words per NodeU
+        uint4 *nc = (uint4 *)(sat + st);
+        ncache = nc;
+        const NodeU *nodes_u = (const NodeU *)a.nodes_u;
+        for (int i = tid; i < NC * T; i += TRAV_THREADS) {
+            const int t = i / NC, k = i - t * NC;
+            const int root = a.f.roots[t];
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (root >= 0 && (uint32_t)(root + k) < a.f.n_nodes) v = *(const uint4 *)(nodes_u + root + k);
+            nc[i] = v;
+        }
+        __syncthreads();
+    }
 
-    // ---- phase 3: root->leaf walks.  Work item i = (tree i / n_active, active slot i % n_active), so
-    // the lanes of a wave start in the same tree and share its top-level nodes.  Lanes whose walk
-    // ended are refilled from a workgroup queue: one ballot finds them, one LDS atomic per wave
-    // reserves that many items, each lane takes base + (its rank among the refilling lanes).
-    // Every lane leaves the loop once the queue is exhausted and its own walk hit a leaf; trees
-    // are validated acyclic on the host, so every walk ends.
+    STAMP(4)
+    // ---- phase 3: root->leaf walks.  Work item k = (tree k / n_active, active slot k % n_active),
+    // lane = k mod 1024: the lanes of a wave walk the SAME tree for NEIGHBOURING windows (4 px apart),
+    // which see almost the same pixels, so they mostly follow the same path: node fetches collapse
+    // to a few addresses per wave and walks end within a level or two of each other.
+    // (A ballot-compacted refill of finished lanes was built and measured: it lengthens this phase
+    // by 25-50 % because it breaks exactly that coherence -- DESIGN.md section 4.)  Trees are
+    // validated acyclic on the host, so every walk ends.
     const int total = n_active * T;
     {
         const NodeU *nodes_u = (const NodeU *)a.nodes_u;
-        int item = -1;      // -1: needs work, -2: queue exhausted
-        int cur = 0, pbase = 0, lslot = 0;
-        for (;;) {
-            bool need = item == -1;
-            uint64_t m = __ballot(need);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = (int)atomicAdd(&misc[1], (uint32_t)__popcll(m));
-                base = __shfl(base, 0);
-                if (need) {
-                    int k = base + __popcll(m & lanemask_lt());
-                    if (k < total) {
-                        int t = k / n_active, slot = k - t * n_active;
-                        int p = (int)active[slot];
-                        int pxi = p % cx, pyi = p / cx;
-                        pbase = pyi * a.step * ss + pxi * a.step;
-                        lslot = p * T + t;
-                        cur = a.f.roots[t];
-                        item = k;
-                        if (cur < 0) { leaf[lslot] = ~cur; item = -1; }   // single-leaf tree
-                    } else {
-                        item = -2;
-                    }
-                }
-            }
-            if (__ballot(item >= 0) == 0ull) {
-                if (__ballot(item == -1) == 0ull) break;   // all lanes exhausted
-                continue;                                   // some lane refills next round
-            }
-            if (item >= 0) {
-                // HoughTreeFunctions::binarize (houghforest.rs:185-193) with O(1) rect sums
+        for (int k = tid; k < total; k += TRAV_THREADS) {
+            const int t = k / n_active, slot = k - t * n_active;
+            const int p = (int)active[slot];
+            const int pyi = p / cx, pxi = p - pyi * cx;
+            const uint32_t *sp = sat + pyi * a.step * ss + pxi * a.step;
+            int cur = a.f.roots[t];
+            const int croot = cur, cbase = t * NC;
+            while (cur >= 0) {
                 if (UNI) {
-                    const uint4 nd = *(const uint4 *)(nodes_u + cur);
-                    const uint32_t *sp = sat + pbase;
+                    // HoughTreeFunctions::binarize (houghforest.rs:185-193): two box sums, integer test
+                    const uint32_t rel = (uint32_t)(cur - croot);
+                    const uint4 nd = rel < (uint32_t)NC ? ncache[cbase + rel] : *(const uint4 *)(nodes_u + cur);
                     const uint32_t s1 = sp[nd.x & 0x3fffu], s2 = sp[(nd.x >> 14) & 0x3fffu];
                     const int32_t d = (int32_t)s1 - (int32_t)s2, ilo = (int32_t)nd.y;
                     bool one = d > ilo;
@@ -518,27 +543,27 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
                     }
                     cur = one ? (int)nd.w : (int)nd.z;
                 } else {
+                    // general rectangles: 8 SAT corners, IEEE f64 means (types.rs:317-339)
                     const uint4 *np = (const uint4 *)(a.f.nodes + cur);
-                    uint4 n0 = np[0], n1 = np[1];
-                    int ax0 = n0.x & 0xffff, ay0 = n0.x >> 16, ax1 = n0.y & 0xffff, ay1 = n0.y >> 16;
-                    int bx0 = n0.z & 0xffff, by0 = n0.z >> 16, bx1 = n0.w & 0xffff, by1 = n0.w >> 16;
-                    double thr = __hiloint2double((int)n1.y, (int)n1.x);
-                    const uint32_t *sp = sat + pbase;
-                    uint32_t s1 = sp[ay1 * ss + ax1] - sp[ay0 * ss + ax1] - sp[ay1 * ss + ax0] + sp[ay0 * ss + ax0];
-                    uint32_t s2 = sp[by1 * ss + bx1] - sp[by0 * ss + bx1] - sp[by1 * ss + bx0] + sp[by0 * ss + bx0];
-                    uint32_t c1 = (uint32_t)((ax1 - ax0) * (ay1 - ay0)), c2 = (uint32_t)((bx1 - bx0) * (by1 - by0));
-                    double a1 = c1 ? __ddiv_rn((double)s1, (double)c1) : 0.0;   // types.rs:335-338
-                    double a2 = c2 ? __ddiv_rn((double)s2, (double)c2) : 0.0;
-                    bool one = __dsub_rn(a1, a2) > thr;
-                    cur = one ? (int)n1.w : (int)n1.z;
+                    const uint4 n0 = np[0], n1 = np[1];
+                    const int ax0 = n0.x & 0xffff, ay0 = n0.x >> 16, ax1 = n0.y & 0xffff, ay1 = n0.y >> 16;
+                    const int bx0 = n0.z & 0xffff, by0 = n0.z >> 16, bx1 = n0.w & 0xffff, by1 = n0.w >> 16;
+                    const double thr = __hiloint2double((int)n1.y, (int)n1.x);
+                    const uint32_t s1 = sp[ay1 * ss + ax1] - sp[ay0 * ss + ax1] - sp[ay1 * ss + ax0] + sp[ay0 * ss + ax0];
+                    const uint32_t s2 = sp[by1 * ss + bx1] - sp[by0 * ss + bx1] - sp[by1 * ss + bx0] + sp[by0 * ss + bx0];
+                    const uint32_t c1 = (uint32_t)((ax1 - ax0) * (ay1 - ay0)), c2 = (uint32_t)((bx1 - bx0) * (by1 - by0));
+                    const double a1 = c1 ? __ddiv_rn((double)s1, (double)c1) : 0.0;   // types.rs:335-338
+                    const double a2 = c2 ? __ddiv_rn((double)s2, (double)c2) : 0.0;
+                    cur = (__dsub_rn(a1, a2) > thr) ? (int)n1.w : (int)n1.z;
                 }
-                if (cur < 0) { leaf[lslot] = ~cur; item = -1; }
             }
+            leaf[p * T + t] = ~cur;
         }
     }
     __syncthreads();
 
     if (a.stop_phase == 4) return;
+    STAMP(5)
     // ---- phase 4: mean leaf probability in tree order (prediction.rs:582-584), hit records.
     // The SAT / box image is dead now; its LDS is reused as scratch for the (patch, tree) pairs so
     // that every dependent global load of this phase is issued by a different thread.
@@ -605,6 +630,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             ((int4 *)(dbox + o))[1] = make_int4(f32_as_i32(__fsub_rn(q1, mn1)), f32_as_i32(__fsub_rn(q2, mn2)), (int)t1.z, (int)t1.w);
             *(uint4 *)(drot + o) = make_uint4(t2v.y, t2v.z, t2v.w, t3.x);                           // rlo, rhi, rb, n_rot
         }
+        STAMP(6)
         return;
     }
     // ---- fallback for forests too large for the scratch (n_active * T * 12 bytes > SAT): one thread per patch

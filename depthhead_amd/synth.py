@@ -218,3 +218,139 @@ class ModelParams:
         nx = len(range(lw, w - rw, self.stepwidth)) if w >= self.subimage_width else 0
         ny = len(range(lh, h - rh, self.stepwidth)) if h >= self.subimage_height else 0
         return nx, ny
+
+
+# ------------------------------------------------------------------ a forest fitted to synthetic subjects
+TRAIN_SEED_BASE = 0x7A110000
+
+
+def _frame_sat(img: np.ndarray) -> np.ndarray:
+    s = np.zeros((img.shape[0] + 1, img.shape[1] + 1), dtype=np.int64)
+    s[1:, 1:] = img.astype(np.int64).cumsum(0).cumsum(1)
+    return s
+
+
+def fit_forest(n_trees: int = 10, max_depth: int = 15, seed: int = FOREST_SEED_BASE, n_frames: int = 48,
+               per_frame: int = 160, subset: int = 6000, n_candidates: int = 8, min_subset: int = 20,
+               patch: tuple[int, int] = (80, 80), rect_scale: float = 0.3, w: int = 640, h: int = 480,
+               steepness: float = 5.0, max_votes: int = 40) -> Forest:
+    """A small Hough forest actually FITTED to synthetic subjects, so that its votes are coherent
+    (leaves reached by head patches point at the head centre) and the vote / mean-shift stages see
+    a realistic load.  This mirrors the shape of the reference's trainer -- patches labelled by a
+    head mask, 3-D offset + rotation truths, random rectangle-pair features with thresholds in
+    [-256, 256), best-of-N by an entropy + regression-uncertainty score, stop below `min_subset`
+    samples / at `max_depth` / when no positive remains (src/hough/prediction.rs:145-234,
+    src/hough/houghforest.rs:204-310) -- but it is a generator for benchmarks and tests, not a
+    restatement: training is outside the scope of this repository.
+    """
+    pw, ph = patch
+    rw, rh = int(pw * rect_scale), int(ph * rect_scale)
+    lw, lh = pw // 2, ph // 2
+    rng = SplitMix(seed ^ 0xF17F0E57)
+    f = 560.0 * w / 640.0
+    cx0, cy0 = w / 2.0, h / 2.0
+    # ---- samples
+    sats, S_frame, S_x, S_y, S_pos, S_off, S_rot = [], [], [], [], [], [], []
+    gx, gy = np.arange(lw, w - (pw - lw), 4), np.arange(lh, h - (ph - lh), 4)
+    GX, GY = np.meshgrid(gx, gy)
+    GX, GY = GX.ravel(), GY.ravel()
+    for i in range(n_frames):
+        fseed = TRAIN_SEED_BASE + i
+        img = biwi_like(w, h, fseed)
+        z0, hx, hy, rot = head_truth(w, h, fseed)
+        sat = _frame_sat(img)
+        sats.append(sat)
+        ox, oy = GX - lw, GY - lh
+        psum = sat[oy + ph, ox + pw] - sat[oy, ox + pw] - sat[oy + ph, ox] + sat[oy, ox]
+        nonbg = psum > 0                                                        # prediction.rs:181-203: only non-background patches
+        zc = img[GY, GX].astype(np.float64)
+        rp = 95.0 * f / z0
+        inhead = ((GX - hx) ** 2 + (GY - hy) ** 2 < (0.85 * rp) ** 2) & (zc > 0)
+        pos_idx = np.flatnonzero(nonbg & inhead)
+        neg_idx = np.flatnonzero(nonbg & ~inhead)
+        for idx, want, label in ((pos_idx, per_frame // 2, True), (neg_idx, per_frame // 2, False)):
+            if idx.size == 0:
+                continue
+            pick = idx[(rng.uniform(min(want, idx.size)) * idx.size).astype(np.int64)]
+            xs, ys, zs = GX[pick].astype(np.float64), GY[pick].astype(np.float64), zc[pick]
+            p3 = np.stack([(xs - cx0) / f * zs, (ys - cy0) / f * zs, zs], axis=1)
+            head3 = np.array([(hx - cx0) / f * z0, (hy - cy0) / f * z0, z0])
+            S_frame.append(np.full(pick.size, i)); S_x.append(GX[pick] - lw); S_y.append(GY[pick] - lh)
+            S_pos.append(np.full(pick.size, label)); S_off.append(p3 - head3); S_rot.append(np.tile(rot, (pick.size, 1)))
+    S_frame, S_x, S_y = np.concatenate(S_frame), np.concatenate(S_x), np.concatenate(S_y)
+    S_pos, S_off, S_rot = np.concatenate(S_pos), np.concatenate(S_off), np.concatenate(S_rot)
+    SAT = np.stack(sats)
+    n_samples = S_frame.size
+
+    def rect_avg(sel, r):
+        fr, x, y = S_frame[sel], S_x[sel], S_y[sel]
+        s = SAT[fr, y + r[3], x + r[2]] - SAT[fr, y + r[1], x + r[2]] - SAT[fr, y + r[3], x + r[0]] + SAT[fr, y + r[1], x + r[0]]
+        return s / float((r[2] - r[0]) * (r[3] - r[1]))
+
+    def neg_entropy(pos):
+        p = pos.mean() if pos.size else 0.0
+        return (p * np.log(p) if p > 0 else 0.0) + ((1 - p) * np.log(1 - p) if p < 1 else 0.0)
+
+    def reg_unc(sel):
+        good = sel[S_pos[sel]]
+        if good.size < 2:
+            return 0.0
+        return float(np.log(S_off[good].var(axis=0, ddof=1).sum() + S_rot[good].var(axis=0, ddof=1).sum() + 1.0))
+
+    roots = np.zeros(n_trees, dtype=np.int32)
+    all_nodes, leaf_prob, leaf_off, leaf_rot = [], [], [], []
+    for t in range(n_trees):
+        sub = (rng.uniform(min(subset, n_samples)) * n_samples).astype(np.int64)
+        nodes_t = []                     # (r1, r2, thr, child_zero, child_one) with local indices, fixed up below
+        frontier = [(sub, 0, -1, 0)]     # (samples, depth, parent, which)
+        root_val = None
+        while frontier:
+            nxt = []
+            for sel, depth, parent, which in frontier:
+                pos = S_pos[sel]
+                is_leaf = depth >= max_depth or sel.size < min_subset or not pos.any()     # houghforest.rs:302-310
+                best = None
+                if not is_leaf:
+                    fac = 1.0 - np.exp(-depth / steepness)
+                    for _ in range(n_candidates):
+                        u = rng.uniform(5)
+                        r1x, r1y = int(u[0] * (pw - rw)), int(u[1] * (ph - rh))
+                        r2x, r2y = int(u[2] * (pw - rw)), int(u[3] * (ph - rh))
+                        r1, r2 = (r1x, r1y, r1x + rw, r1y + rh), (r2x, r2y, r2x + rw, r2y + rh)
+                        thr = u[4] * 512.0 - 256.0
+                        one = rect_avg(sel, r1) - rect_avg(sel, r2) > thr
+                        n1 = int(one.sum())
+                        if n1 == 0 or n1 == sel.size:
+                            continue
+                        l, r = sel[~one], sel[one]
+                        wl, wr = l.size / sel.size, r.size / sel.size
+                        score = -(wl * neg_entropy(S_pos[l]) + wr * neg_entropy(S_pos[r])) + fac * (wl * reg_unc(l) + wr * reg_unc(r))
+                        if best is None or score < best[0]:
+                            best = (score, r1, r2, thr, l, r)
+                    is_leaf = best is None
+                if is_leaf:
+                    good = sel[pos][:max_votes]
+                    val = ~len(leaf_prob)
+                    leaf_prob.append(pos.mean() if sel.size else 0.0)
+                    leaf_off.append(S_off[good]); leaf_rot.append(S_rot[good])
+                else:
+                    val = len(all_nodes) + len(nodes_t)
+                    nodes_t.append([best[1], best[2], best[3], 0, 0])
+                    nxt.append((best[4], depth + 1, len(nodes_t) - 1, 0))
+                    nxt.append((best[5], depth + 1, len(nodes_t) - 1, 1))
+                if parent < 0:
+                    root_val = val
+                else:
+                    nodes_t[parent][3 + which] = val
+            frontier = nxt
+        roots[t] = root_val
+        all_nodes.extend(nodes_t)
+    nodes = np.zeros(len(all_nodes), dtype=NODE_DTYPE)
+    for i, (r1, r2, thr, cz, co) in enumerate(all_nodes):
+        nodes[i] = (r1, r2, thr, cz, co)
+    n_votes = np.array([len(o) for o in leaf_off], dtype=np.int64)
+    begin = np.zeros(len(leaf_prob) + 1, dtype=np.uint32)
+    np.cumsum(n_votes, out=begin[1:])
+    offsets = np.concatenate(leaf_off).astype(np.float32) if n_votes.sum() else np.zeros((0, 3), dtype=np.float32)
+    rotations = np.concatenate(leaf_rot).astype(np.float64) if n_votes.sum() else np.zeros((0, 3))
+    return Forest(roots, nodes, np.array(leaf_prob), begin, begin.copy(), offsets, rotations)
