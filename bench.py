@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--forest", choices=["fitted", "random"], default="fitted",
                     help="fitted: trainer-sized forest fitted to synthetic subjects (coherent votes, the stand-in for the "
                          "unavailable pretrained forest); random: 13x larger random-split stress forest")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI (the real multi-GPU path); gloo = rehearsal of the N>1 control flow "
+                         "with every rank on one device (poses staged through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
     return ap.parse_args()
@@ -67,13 +70,18 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(1)
+    if args.backend == "gloo":
+        local_rank = 0                                            # rehearsal: every rank shares device 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
 
     from depthhead_amd import synth
     from depthhead_amd._lib import POSE_DTYPE
@@ -92,7 +100,8 @@ def main():
     frames_np = np.concatenate([distinct] * ((NF + nd - 1) // nd))[:NF]
     frames = torch.from_numpy(frames_np.view(np.int16)).to(dev)          # resident in HBM before timing
     poses = torch.zeros(NF * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * NF * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev) if world > 1 else None
+    gdev = dev if args.backend == "nccl" else torch.device("cpu")
+    gathered = torch.zeros(world * NF * POSE_DTYPE.itemsize, dtype=torch.uint8, device=gdev) if world > 1 else None
 
     hp = HoughPrediction(forest, model, device=local_rank)
     hp.reserve(NF, W, H)
@@ -101,7 +110,7 @@ def main():
     def step():
         hp.predict_batch_device(frames.data_ptr(), NF, W, H, intr, poses.data_ptr(), stream=stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, poses)                 # RCCL gather of the pose records
+            dist.all_gather_into_tensor(gathered, poses if args.backend == "nccl" else poses.cpu())   # gather of the pose records
 
     def fence():
         if world > 1:
@@ -117,7 +126,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -126,8 +126,8 @@ extern "C" int dh_forest_create(const dh_forest_desc *d, dh_forest **out) {
         }
     }
     for (uint32_t L = 0; L < NL; ++L)
-        if (f->off_begin[L + 1] - f->off_begin[L] >= (1u << 24) || f->rot_begin[L + 1] - f->rot_begin[L] >= (1u << 24))
-            return bad(DH_EFOREST, "leaf %ld: more than 2^24 votes", L);
+        if (f->off_begin[L + 1] - f->off_begin[L] >= (1u << 24) || f->rot_begin[L + 1] - f->rot_begin[L] >= (1u << 16))
+            return bad(DH_EFOREST, "leaf %ld: more than 2^24 offset or 2^16 rotation votes", L);
     // ---- one rectangle size for the whole forest? (the in-tree trainer's geometry)
     if (NN > 0) {
         const dh_node &n0 = f->nodes[0];
@@ -195,6 +195,9 @@ extern "C" int dh_patch_grid(const dh_params *p, int w, int h, int *nx, int *ny)
 }
 
 // ------------------------------------------------------------------ predictor
+#define DH_MAX_CHUNKS 8
+#define DH_MIN_CHUNK_FRAMES 16
+
 struct dh_predictor {
     int device = 0;
     dh_params params{};
@@ -207,6 +210,9 @@ struct dh_predictor {
     void *nodes_u = nullptr;     // 16-byte compact nodes for the current ss_row (uniform path)
     int nodes_u_ss = 0;
     hipStream_t own_stream = nullptr;
+    int chunks = 1;                       // sub-batches per call (env DH_CHUNKS)
+    hipStream_t aux_stream[DH_MAX_CHUNKS - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[DH_MAX_CHUNKS - 1] = {};
     // workspace
     Geom geom;
     int cap_frames = 0;
@@ -305,6 +311,9 @@ extern "C" int dh_predictor_destroy(dh_predictor *p) {
     for (void *q : p->forest_allocs) (void)hipFree(q);
     if (p->kern_ord) (void)hipFree(p->kern_ord);
     for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    for (auto &e : p->ev_join) if (e) (void)hipEventDestroy(e);
+    for (auto &st : p->aux_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     delete p;
     return DH_OK;
@@ -347,6 +356,8 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     STEP(dev_alloc(p, &d.leaf_flags, p->n_leaves, true));
     STEP(dev_alloc(p, &d.rot_bin, p->n_rot, true));
     STEP(dev_alloc(p, &d.rot_rough, p->n_rot, true));
+    STEP(dev_alloc(p, &d.rot_mult, p->n_rot, true));
+    STEP(dev_alloc(p, &d.rough_mult, p->n_rot, true));
     STEP(dev_alloc(p, &d.off_min, (size_t)p->n_leaves * 3, true));
     STEP(dev_alloc(p, &d.off_max, (size_t)p->n_leaves * 3, true));
     STEP(dev_alloc(p, &d.rbin_box, p->n_leaves, true));
@@ -364,6 +375,13 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     if (rc == DH_OK) rc = build_kernel_table(p);
     for (auto &e : p->ev)
         if (rc == DH_OK) hipstep(hipEventCreate(&e), "hipEventCreate");
+    p->chunks = 1;   // measured on MI355X: forked sub-batches do not overlap usefully (1.016 vs 1.022 ms), kept as a knob
+    if (const char *e = getenv("DH_CHUNKS")) p->chunks = std::max(1, std::min(DH_MAX_CHUNKS, atoi(e)));
+    if (rc == DH_OK) hipstep(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming), "hipEventCreate");
+    for (int i = 0; i < DH_MAX_CHUNKS - 1; ++i) {
+        if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->aux_stream[i], hipStreamNonBlocking), "hipStreamCreate");
+        if (rc == DH_OK) hipstep(hipEventCreateWithFlags(&p->ev_join[i], hipEventDisableTiming), "hipEventCreate");
+    }
     if (rc != DH_OK) {
         char keep[sizeof g_err];
         memcpy(keep, g_err, sizeof keep);
@@ -479,29 +497,20 @@ extern "C" int dh_predictor_reserve(dh_predictor *p, int n, int w, int h) {
     return reserve(p, n, w, h);
 }
 
-extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
-                                       const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
-                                       dh_pose *out, void *stream_) {
-    if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_batch_device: NULL argument");
-    if (n == 0) return DH_OK;
-    int rc = reserve(p, n, w, h);
-    if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream_;
+// Enqueue the three kernels for frames [f0, f0 + n) of the batch on stream s.
+static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n, int w, int h, const float K[9],
+                         const float kinv[9], const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
+                         dh_pose *out, hipStream_t s, bool profile) {
     const Geom &g = p->geom;
-    const int N = n;
-    uint32_t *hit_count = p->counters;
-    uint32_t *pos_grid = p->counters + p->cap_frames;
-    uint32_t *rot_grid = pos_grid + (size_t)p->cap_frames * DH_POSGRID;
-
-    HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3) * sizeof(uint32_t), s));
-
-    float kinv[9];
-    mat3_inv_f32(K, kinv);   // cached in a RefCell by the reference (types.rs:436-441)
-
-    if (p->profiling) HIP_TRY(hipEventRecord(p->ev[0], s));
+    uint32_t *hit_count = p->counters + f0;
+    uint32_t *pos_grid = p->counters + p->cap_frames + (size_t)f0 * DH_POSGRID;
+    uint32_t *rot_grid = p->counters + p->cap_frames + (size_t)p->cap_frames * DH_POSGRID + (size_t)f0 * DH_GRID3;
+    const size_t hoff = (size_t)f0 * p->hits_cap;
+    const uint16_t *fr = frames + (size_t)f0 * w * h;
+    if (profile) HIP_TRY(hipEventRecord(p->ev[0], s));
     if (g.npatch > 0) {
         TraverseArgs ta{};
-        ta.frames = frames; ta.n_frames = N; ta.w = w; ta.h = h;
+        ta.frames = fr; ta.n_frames = n; ta.w = w; ta.h = h;
         ta.step = (int)p->params.stepwidth; ta.sw = (int)p->params.subimage_width; ta.sh = (int)p->params.subimage_height;
         ta.lw = ta.sw / 2; ta.lh = ta.sh / 2;
         ta.nx = g.nx; ta.ny = g.ny; ta.px = g.px; ta.py = g.py; ta.tiles_x = g.tiles_x; ta.tiles_y = g.tiles_y;
@@ -521,37 +530,81 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
             }
             ta.dbg_stamps = stamps;
         }
-        memcpy(ta.kinv, kinv, sizeof kinv);
+        memcpy(ta.kinv, kinv, 9 * sizeof(float));
         ta.f = p->dev;
-        ta.hits = p->hits; ta.hit_box = p->hit_box; ta.hit_rot = p->hit_rot; ta.hit_count = hit_count; ta.hits_cap = p->hits_cap;
-        ta.dbg_leaf = p->debug ? p->dbg_leaf : nullptr;
-        ta.dbg_flags = p->debug ? p->dbg_flags : nullptr;
+        ta.hits = p->hits + hoff; ta.hit_box = p->hit_box + hoff; ta.hit_rot = p->hit_rot + hoff;
+        ta.hit_count = hit_count; ta.hits_cap = p->hits_cap;
+        ta.dbg_leaf = p->debug ? p->dbg_leaf + (size_t)f0 * g.npatch * p->n_trees : nullptr;
+        ta.dbg_flags = p->debug ? p->dbg_flags + (size_t)f0 * g.npatch : nullptr;
         HIP_TRY(dh_launch_traverse(ta, g.lds, s));
     }
-    if (p->profiling) HIP_TRY(hipEventRecord(p->ev[1], s));
+    if (profile) HIP_TRY(hipEventRecord(p->ev[1], s));
     {
         VoteArgs va{};
-        va.n_frames = N; va.w = w; va.h = h;
+        va.n_frames = n; va.w = w; va.h = h;
         memcpy(va.k, K, sizeof va.k);
-        va.f = p->dev; va.hits = p->hits; va.hit_box = p->hit_box; va.hit_rot = p->hit_rot; va.hit_count = hit_count; va.hits_cap = p->hits_cap;
+        va.f = p->dev; va.hits = p->hits + hoff; va.hit_box = p->hit_box + hoff; va.hit_rot = p->hit_rot + hoff;
+        va.hit_count = hit_count; va.hits_cap = p->hits_cap;
         va.pos_grid = pos_grid; va.rot_grid = rot_grid;
         HIP_TRY(dh_launch_vote(va, s));
     }
-    if (p->profiling) HIP_TRY(hipEventRecord(p->ev[2], s));
+    if (profile) HIP_TRY(hipEventRecord(p->ev[2], s));
     {
         ClusterArgs ca{};
-        ca.frames = frames; ca.n_frames = N; ca.w = w; ca.h = h;
-        memcpy(ca.kinv, kinv, sizeof kinv);
-        ca.f = p->dev; ca.hits = p->hits; ca.hit_box = p->hit_box; ca.hit_rot = p->hit_rot; ca.hit_count = hit_count; ca.hits_cap = p->hits_cap;
+        ca.frames = fr; ca.n_frames = n; ca.w = w; ca.h = h;
+        memcpy(ca.kinv, kinv, 9 * sizeof(float));
+        ca.f = p->dev; ca.hits = p->hits + hoff; ca.hit_box = p->hit_box + hoff; ca.hit_rot = p->hit_rot + hoff;
+        ca.hit_count = hit_count; ca.hits_cap = p->hits_cap;
         ca.pos_grid = pos_grid; ca.rot_grid = rot_grid; ca.kern_ord = p->kern_ord;
         ca.iterations = p->params.meanshift_iterations;
-        ca.midp_guess = midp_guess; ca.rot_guess = rot_guess; ca.guess_mask = guess_mask;
-        ca.out = out;
+        ca.midp_guess = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
+        ca.rot_guess = rot_guess ? rot_guess + (size_t)f0 * 3 : nullptr;
+        ca.guess_mask = guess_mask ? guess_mask + f0 : nullptr;
+        ca.out = out + f0;
         if (p->debug) { ca.dbg_guess = p->dbg_guess; ca.dbg_trace = p->dbg_trace; ca.dbg_steps = p->dbg_steps; }
         HIP_TRY(dh_launch_cluster(ca, s));
     }
-    if (p->profiling) { HIP_TRY(hipEventRecord(p->ev[3], s)); p->ev_valid = true; }
-    p->last_n = N;
+    if (profile) { HIP_TRY(hipEventRecord(p->ev[3], s)); p->ev_valid = true; }
+    return DH_OK;
+}
+
+extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                                       const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
+                                       dh_pose *out, void *stream_) {
+    if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_batch_device: NULL argument");
+    if (n == 0) return DH_OK;
+    int rc = reserve(p, n, w, h);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream_;
+    HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3) * sizeof(uint32_t), s));
+    float kinv[9];
+    mat3_inv_f32(K, kinv);   // cached in a RefCell by the reference (types.rs:436-441)
+
+    // The walk kernel is throughput-bound, the vote / mean-shift kernels are latency-bound with few
+    // waves: the batch is cut into sub-batches that run on forked streams (joined back into the
+    // caller's stream before returning), so the mean shift of one sub-batch hides under the tree
+    // walks of the next.  Taps and per-kernel profiling need one ordered pass.
+    int chunks = p->chunks;
+    if (p->profiling || p->debug || n < 2 * DH_MIN_CHUNK_FRAMES) chunks = 1;
+    chunks = std::min(chunks, n / DH_MIN_CHUNK_FRAMES);
+    if (chunks <= 1) {
+        rc = enqueue_range(p, frames, 0, n, w, h, K, kinv, midp_guess, rot_guess, guess_mask, out, s, p->profiling);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(hipEventRecord(p->ev_fork, s));
+        for (int c = 0; c < chunks; ++c) {
+            const int f0 = (int)((long long)n * c / chunks), f1 = (int)((long long)n * (c + 1) / chunks);
+            hipStream_t cs = c == 0 ? s : p->aux_stream[c - 1];
+            if (c > 0) HIP_TRY(hipStreamWaitEvent(cs, p->ev_fork, 0));
+            rc = enqueue_range(p, frames, f0, f1 - f0, w, h, K, kinv, midp_guess, rot_guess, guess_mask, out, cs, false);
+            if (rc) return rc;
+            if (c > 0) {
+                HIP_TRY(hipEventRecord(p->ev_join[c - 1], cs));
+                HIP_TRY(hipStreamWaitEvent(s, p->ev_join[c - 1], 0));
+            }
+        }
+    }
+    p->last_n = n;
     p->last_frames = frames;
     p->dbg_valid = p->debug;
     return DH_OK;

@@ -23,7 +23,7 @@ struct __attribute__((aligned(16))) LeafTpl {
     uint32_t fc;                 // LF_* | n_offsets << 8
     uint32_t ob;                 // first offset vote
     uint32_t rlo, rhi;           // rotation-bin bounding box (rlo = 0xFFFFFFFF: no rotation votes)
-    uint32_t rb, n_rot;          // rotation votes
+    uint32_t rb, n_rot;          // rotation cells: first index, n_distinct_fine | n_distinct_rough << 16
     uint32_t pad[3];
 };
 
@@ -41,8 +41,12 @@ struct DevForest {
     // prepared
     uint32_t *leaf_v;      // valtoadd                                   (prediction.rs:594-595)
     uint8_t  *leaf_flags;  // LF_*
-    uint32_t *rot_bin;     // per rotation vote: r1 | r2<<8 | r3<<16      (:605-627)
-    uint16_t *rot_rough;   // per rotation vote: index into the 20^3 grid (:630-636)
+    // rotation votes depend only on the leaf, and a leaf's votes fall into few distinct cells: each
+    // leaf's slice [rot_begin, rot_begin + n) of these arrays holds its DISTINCT cells + multiplicities
+    uint32_t *rot_bin;     // distinct fine bins r1 | r2<<8 | r3<<16      (:605-627)
+    uint16_t *rot_mult;    // votes per distinct fine bin
+    uint16_t *rot_rough;   // distinct indices into the 20^3 guess grid   (:630-636)
+    uint16_t *rough_mult;  // votes per distinct guess-grid cell
     float    *off_min;     // per leaf, 3 floats: component-wise min of its offsets (-inf if non-finite)
     float    *off_max;     // per leaf, 3 floats                                     (+inf if non-finite)
     uint32_t *rbin_box;    // per leaf: component-wise minimum of its rotation bins, r1 | r2<<8 | r3<<16
@@ -70,8 +74,8 @@ struct __attribute__((aligned(16))) HitBox {
 struct __attribute__((aligned(16))) HitRot {
     uint32_t lo;       // r1 | r2<<8 | r3<<16 minima; 0xFFFFFFFF when the leaf casts no rotation vote
     uint32_t hi;
-    uint32_t rb;       // index of the leaf's first rotation vote
-    uint32_t n_rot;
+    uint32_t rb;       // index of the leaf's first rotation cell
+    uint32_t n_rot;    // distinct fine bins | distinct guess-grid cells << 16
 };
 
 struct TraverseArgs {

@@ -136,7 +136,10 @@ __global__ void __launch_bounds__(256) k_leaf_prepare(DevForest f) {
                 for (int k = 0; k < 3; ++k) { omin[k] = -INFINITY; omax[k] = INFINITY; }
         }
     }
-    // ---- rotation bins (:605-632); host validation guarantees [0,120) for leaves that can vote
+    // ---- rotation bins (:605-632); host validation guarantees [0,120) for leaves that can vote.
+    // The leaf's votes are reduced to its distinct fine bins / guess-grid cells with multiplicities
+    // (v * mult wraps exactly like mult separate u32 adds of v).
+    uint32_t n_fine = 0, n_rough = 0;
     for (uint32_t i = rb; i < re; ++i) {
         uint32_t packed = 0, rough = 0, mul = 1;
         for (int k = 0; k < 3; ++k) {
@@ -147,13 +150,18 @@ __global__ void __launch_bounds__(256) k_leaf_prepare(DevForest f) {
             uint32_t rg = ru * DH_GRID / DH_ROTPARTS;
             uint32_t rc = ru > 255u ? 255u : ru;    // only reachable for leaves that never vote
             packed |= rc << (8 * k);
-            rough += (rg < DH_GRID ? rg : 0u) * mul;
+            rough += (rg < DH_GRID ? rg : 0u) * mul;   // x + 20*y + 400*z (meanshift.rs:78-88)
             mul *= DH_GRID;
             if (rc < bmin[k]) bmin[k] = rc;
             if (rc > bmax[k]) bmax[k] = rc;
         }
-        f.rot_bin[i] = packed;
-        f.rot_rough[i] = (uint16_t)rough;   // x + 20*y + 400*z (meanshift.rs:78-88)
+        uint32_t j = 0;
+        for (; j < n_fine; ++j) if (f.rot_bin[rb + j] == packed) break;
+        if (j == n_fine) { f.rot_bin[rb + j] = packed; f.rot_mult[rb + j] = 0; n_fine++; }
+        f.rot_mult[rb + j]++;
+        for (j = 0; j < n_rough; ++j) if (f.rot_rough[rb + j] == (uint16_t)rough) break;
+        if (j == n_rough) { f.rot_rough[rb + j] = (uint16_t)rough; f.rough_mult[rb + j] = 0; n_rough++; }
+        f.rough_mult[rb + j]++;
     }
     f.leaf_v[L] = v;
     f.leaf_flags[L] = (uint8_t)flags;
@@ -164,7 +172,7 @@ __global__ void __launch_bounds__(256) k_leaf_prepare(DevForest f) {
     for (int k = 0; k < 3; ++k) { t.omin[k] = omin[k]; t.omax[k] = omax[k]; }
     t.v = v; t.fc = flags | (n_off << 8); t.ob = ob;
     t.rlo = (flags & LF_ROT) ? f.rbin_box[L] : 0xFFFFFFFFu; t.rhi = f.rbin_box_hi[L];
-    t.rb = rb; t.n_rot = n_rot; t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    t.rb = rb; t.n_rot = n_fine | (n_rough << 16); t.pad[0] = t.pad[1] = t.pad[2] = 0;
     f.tpl[L] = t;
 }
 
@@ -705,7 +713,7 @@ hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream
 // Coarse guess grids (prediction.rs:529-533, :630-636, :661-676).  Each workgroup owns a slice of
 // one frame's hit records, accumulates in LDS and flushes its non-zero cells with integer atomics
 // (exact, order-free, wrapping like the reference's release-mode u32 `+=`).
-#define VOTE_THREADS 256
+#define VOTE_THREADS 512
 #define VOTE_SLICES 8
 
 __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
@@ -730,9 +738,10 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         const uint4 rr = *(const uint4 *)(hr + i);
         const uint32_t v = (uint32_t)b1.z, fc = (uint32_t)b1.w;
         if (fc & LF_ROT)
-            for (uint32_t r = rr.z; r < rr.z + rr.w; ++r) atomicAdd(&rot[a.f.rot_rough[r]], v);      // :636
+            for (uint32_t r = rr.z; r < rr.z + (rr.w >> 16); ++r) atomicAdd(&rot[a.f.rot_rough[r]], v * a.f.rough_mult[r]);   // :636
         if (fc & LF_OFF) {
             const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
+            uint32_t last = 0xFFFFFFFFu, acc = 0;      // a leaf's votes mostly share a cell: one atomic per run
             for (uint32_t o = ob; o < oe; ++o) {
                 const float *of = a.f.offsets + (size_t)o * 3;
                 float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // :647
@@ -742,10 +751,17 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
                 float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
                 float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;               // :662
                 float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;               // :663
-                uint64_t gx = f32_as_usize(x2) * DH_GRID / (uint64_t)a.w;                  // :671-672
-                uint64_t gy = f32_as_usize(y2) * DH_GRID / (uint64_t)a.h;
-                atomicAdd(&pos[gy * DH_GRID + gx], v);                                    // :675
+                // x2 in [0, w-1]: the usize arithmetic of :671-674 fits 32 bits
+                uint32_t gx = (uint32_t)f32_as_usize(x2) * DH_GRID / (uint32_t)a.w;        // :671-672
+                uint32_t gy = (uint32_t)f32_as_usize(y2) * DH_GRID / (uint32_t)a.h;
+                const uint32_t idx = gy * DH_GRID + gx;
+                if (idx != last) {
+                    if (acc) atomicAdd(&pos[last], acc);                                  // :675
+                    last = idx; acc = 0;
+                }
+                acc += v;
             }
+            if (acc) atomicAdd(&pos[last], acc);
         }
     }
     __syncthreads();
@@ -932,12 +948,12 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                         if (!range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG)) continue;
                         if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG)) continue;
                         const uint32_t v = vv[j];
-                        for (uint32_t q = r[j].z; q < r[j].z + r[j].w; ++q) {
-                            uint32_t b = a.f.rot_bin[q];                                                                  // prediction.rs:635
+                        for (uint32_t q = r[j].z; q < r[j].z + (r[j].w & 0xffffu); ++q) {
+                            const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                   // prediction.rs:635
                             uint32_t dx = (b & 255u) - (uint32_t)org[0];
                             uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
                             uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
-                            if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], v);
+                            if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
                         }
                     }
                 }
@@ -1067,12 +1083,12 @@ __global__ void __launch_bounds__(256) k_votes_dump(VotesDumpArgs a) {
                 }
             }
         } else if (a.which == 1 && (fc & LF_ROT)) {
-            for (uint32_t r = hr[i].rb; r < hr[i].rb + hr[i].n_rot; ++r) {
+            for (uint32_t r = hr[i].rb; r < hr[i].rb + (hr[i].n_rot & 0xffffu); ++r) {
                 uint32_t b = a.f.rot_bin[r];
                 uint32_t k = atomicAdd(a.count, 1u);
                 if (k < a.cap) {
                     a.out[k * 4 + 0] = (int32_t)(b & 255u); a.out[k * 4 + 1] = (int32_t)((b >> 8) & 255u);
-                    a.out[k * 4 + 2] = (int32_t)((b >> 16) & 255u); a.out[k * 4 + 3] = (int32_t)v;
+                    a.out[k * 4 + 2] = (int32_t)((b >> 16) & 255u); a.out[k * 4 + 3] = (int32_t)(v * a.f.rot_mult[r]);
                 }
             }
         }
