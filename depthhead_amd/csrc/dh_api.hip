@@ -227,6 +227,13 @@ struct dh_predictor {
     float *ws_midp = nullptr;
     double *ws_rot = nullptr;
     uint8_t *ws_mask = nullptr;
+    // leaf-id outputs for predict_mask / the 2-D Hough image, allocated on first use
+    int32_t *aux_leaf = nullptr;
+    uint8_t *aux_flags = nullptr;
+    uint32_t *aux_u32 = nullptr;
+    void *aux_out = nullptr;
+    size_t aux_out_bytes = 0;
+    int aux_cap = 0;
     // taps
     bool debug = false;
     int32_t *dbg_leaf = nullptr;
@@ -292,10 +299,11 @@ static int build_kernel_table(dh_predictor *p) {
 }
 
 static void free_workspace(dh_predictor *p) {
-    void *ptrs[] = {p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
+    void *ptrs[] = {p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
                     p->dbg_flags, p->dbg_guess, p->dbg_trace, p->dbg_steps, p->dbg_votes, p->dbg_vcount};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    p->aux_leaf = nullptr; p->aux_flags = nullptr; p->aux_u32 = nullptr; p->aux_out = nullptr; p->aux_out_bytes = 0; p->aux_cap = 0;
     p->ws_frames = nullptr; p->hits = nullptr; p->hit_box = nullptr; p->hit_rot = nullptr; p->counters = nullptr; p->ws_poses = nullptr; p->ws_midp = nullptr;
     p->ws_rot = nullptr; p->ws_mask = nullptr; p->dbg_leaf = nullptr; p->dbg_flags = nullptr; p->dbg_guess = nullptr;
     p->dbg_trace = nullptr; p->dbg_steps = nullptr; p->dbg_votes = nullptr; p->dbg_vcount = nullptr;
@@ -500,7 +508,8 @@ extern "C" int dh_predictor_reserve(dh_predictor *p, int n, int w, int h) {
 // Enqueue the three kernels for frames [f0, f0 + n) of the batch on stream s.
 static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n, int w, int h, const float K[9],
                          const float kinv[9], const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
-                         dh_pose *out, hipStream_t s, bool profile) {
+                         dh_pose *out, hipStream_t s, bool profile, int32_t *leaf_out = nullptr, uint8_t *flags_out = nullptr,
+                         bool traverse_only = false) {
     const Geom &g = p->geom;
     uint32_t *hit_count = p->counters + f0;
     uint32_t *pos_grid = p->counters + p->cap_frames + (size_t)f0 * DH_POSGRID;
@@ -534,11 +543,12 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.f = p->dev;
         ta.hits = p->hits + hoff; ta.hit_box = p->hit_box + hoff; ta.hit_rot = p->hit_rot + hoff;
         ta.hit_count = hit_count; ta.hits_cap = p->hits_cap;
-        ta.dbg_leaf = p->debug ? p->dbg_leaf + (size_t)f0 * g.npatch * p->n_trees : nullptr;
-        ta.dbg_flags = p->debug ? p->dbg_flags + (size_t)f0 * g.npatch : nullptr;
+        ta.dbg_leaf = leaf_out ? leaf_out : p->debug ? p->dbg_leaf + (size_t)f0 * g.npatch * p->n_trees : nullptr;
+        ta.dbg_flags = flags_out ? flags_out : p->debug ? p->dbg_flags + (size_t)f0 * g.npatch : nullptr;
         HIP_TRY(dh_launch_traverse(ta, g.lds, s));
     }
     if (profile) HIP_TRY(hipEventRecord(p->ev[1], s));
+    if (traverse_only) return DH_OK;
     {
         VoteArgs va{};
         va.n_frames = n; va.w = w; va.h = h;
@@ -610,6 +620,8 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
     return DH_OK;
 }
 
+static int stage_frames(dh_predictor *p, const uint16_t *frames, int n, int w, int h);
+
 extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                                 const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_batch: NULL argument");
@@ -618,18 +630,9 @@ extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, 
     int rc = reserve(p, n, w, h);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(p->device));
-    size_t fbytes = (size_t)n * w * h * sizeof(uint16_t);
-    if (fbytes > p->ws_frames_bytes) {
-        HIP_TRY(hipStreamSynchronize(p->own_stream));
-        if (p->ws_frames) (void)hipFree(p->ws_frames);
-        p->ws_frames = nullptr; p->ws_frames_bytes = 0;
-        size_t want = (size_t)p->cap_frames * w * h * sizeof(uint16_t);
-        rc = dev_alloc(p, &p->ws_frames, want / sizeof(uint16_t));
-        if (rc) return rc;
-        p->ws_frames_bytes = want;
-    }
+    rc = stage_frames(p, frames, n, w, h);
+    if (rc) return rc;
     hipStream_t s = p->own_stream;
-    HIP_TRY(hipMemcpyAsync(p->ws_frames, frames, fbytes, hipMemcpyHostToDevice, s));
     if (midp_guess) HIP_TRY(hipMemcpyAsync(p->ws_midp, midp_guess, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
     if (rot_guess) HIP_TRY(hipMemcpyAsync(p->ws_rot, rot_guess, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     if (guess_mask) HIP_TRY(hipMemcpyAsync(p->ws_mask, guess_mask, (size_t)n, hipMemcpyHostToDevice, s));
@@ -638,6 +641,123 @@ extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, 
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, p->ws_poses, (size_t)n * sizeof(dh_pose), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return DH_OK;
+}
+
+// ------------------------------------------------------------------ predict_mask / 2-D Hough votes
+static int aux_reserve(dh_predictor *p, int n, int w, int h, size_t out_bytes) {
+    int rc = reserve(p, n, w, h);
+    if (rc) return rc;
+    const Geom &g = p->geom;
+    if (p->aux_cap < p->cap_frames || !p->aux_leaf) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (void *q : {(void *)p->aux_leaf, (void *)p->aux_flags, (void *)p->aux_u32}) if (q) (void)hipFree(q);
+        p->aux_leaf = nullptr; p->aux_flags = nullptr; p->aux_u32 = nullptr; p->aux_cap = 0;
+        rc = dev_alloc(p, &p->aux_leaf, (size_t)p->cap_frames * std::max(g.npatch, 1) * p->n_trees);
+        if (rc == DH_OK) rc = dev_alloc(p, &p->aux_flags, (size_t)p->cap_frames * std::max(g.npatch, 1));
+        if (rc == DH_OK) rc = dev_alloc(p, &p->aux_u32, (size_t)p->cap_frames * w * h);
+        if (rc) return rc;
+        p->aux_cap = p->cap_frames;
+    }
+    if (out_bytes > p->aux_out_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (p->aux_out) (void)hipFree(p->aux_out);
+        p->aux_out = nullptr; p->aux_out_bytes = 0;
+        uint8_t *q = nullptr;
+        rc = dev_alloc(p, &q, out_bytes);
+        if (rc) return rc;
+        p->aux_out = q; p->aux_out_bytes = out_bytes;
+    }
+    return DH_OK;
+}
+
+static int aux_run(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint8_t *mask,
+                   uint16_t *hough, hipStream_t s) {
+    const Geom &g = p->geom;
+    float kinv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, kid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (K) mat3_inv_f32(K, kinv);
+    HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * sizeof(uint32_t), s));   // hit counters only
+    HIP_TRY(hipMemsetAsync(p->aux_flags, 0, (size_t)n * std::max(g.npatch, 1), s));
+    int rc = enqueue_range(p, frames, 0, n, w, h, K ? K : kid, kinv, nullptr, nullptr, nullptr, p->ws_poses, s, false,
+                           p->aux_leaf, p->aux_flags, true);
+    if (rc) return rc;
+    AuxArgs a{};
+    a.frames = frames; a.n_frames = n; a.w = w; a.h = h;
+    a.step = (int)p->params.stepwidth; a.sw = (int)p->params.subimage_width; a.sh = (int)p->params.subimage_height;
+    a.lw = a.sw / 2; a.lh = a.sh / 2; a.nx = g.nx; a.ny = g.ny;
+    memcpy(a.k, K ? K : kid, sizeof a.k); memcpy(a.kinv, kinv, sizeof a.kinv);
+    a.f = p->dev; a.leaf = p->aux_leaf; a.flags = p->aux_flags;
+    if (mask) {
+        HIP_TRY(hipMemsetAsync(mask, 0, (size_t)n * w * h, s));          // ImageBuffer::new zero-fills (prediction.rs:852)
+        a.mask = mask;
+        HIP_TRY(dh_launch_mask(a, s));
+    }
+    if (hough) {
+        HIP_TRY(hipMemsetAsync(p->aux_u32, 0, (size_t)n * w * h * sizeof(uint32_t), s));
+        a.hough32 = p->aux_u32;
+        HIP_TRY(dh_launch_hough2d(a, hough, s));
+    }
+    p->last_n = 0;   // the pose taps do not refer to this run
+    return DH_OK;
+}
+
+extern "C" int dh_predict_mask_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask, void *stream) {
+    if (!p || !frames || !mask) return fail(DH_EINVAL, "dh_predict_mask_device: NULL argument");
+    if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
+    int rc = aux_reserve(p, n, w, h, 0);
+    if (rc) return rc;
+    return aux_run(p, frames, n, w, h, nullptr, mask, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int dh_hough_image_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                                     uint16_t *out, void *stream) {
+    if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_hough_image_device: NULL argument");
+    if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
+    int rc = aux_reserve(p, n, w, h, 0);
+    if (rc) return rc;
+    return aux_run(p, frames, n, w, h, K, nullptr, out, (hipStream_t)stream);
+}
+
+static int stage_frames(dh_predictor *p, const uint16_t *frames, int n, int w, int h) {
+    size_t fbytes = (size_t)n * w * h * sizeof(uint16_t);
+    if (fbytes > p->ws_frames_bytes) {
+        HIP_TRY(hipStreamSynchronize(p->own_stream));
+        if (p->ws_frames) (void)hipFree(p->ws_frames);
+        p->ws_frames = nullptr; p->ws_frames_bytes = 0;
+        size_t want = (size_t)p->cap_frames * w * h * sizeof(uint16_t);
+        int rc = dev_alloc(p, &p->ws_frames, want / sizeof(uint16_t));
+        if (rc) return rc;
+        p->ws_frames_bytes = want;
+    }
+    HIP_TRY(hipMemcpyAsync(p->ws_frames, frames, fbytes, hipMemcpyHostToDevice, p->own_stream));
+    return DH_OK;
+}
+
+extern "C" int dh_predict_mask(dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask) {
+    if (!p || !frames || !mask) return fail(DH_EINVAL, "dh_predict_mask: NULL argument");
+    if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t ob = (size_t)n * w * h;
+    int rc = aux_reserve(p, n, w, h, ob);
+    if (rc == DH_OK) rc = stage_frames(p, frames, n, w, h);
+    if (rc == DH_OK) rc = aux_run(p, p->ws_frames, n, w, h, nullptr, (uint8_t *)p->aux_out, nullptr, p->own_stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(mask, p->aux_out, ob, hipMemcpyDeviceToHost, p->own_stream));
+    HIP_TRY(hipStreamSynchronize(p->own_stream));
+    return DH_OK;
+}
+
+extern "C" int dh_hough_image(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *out) {
+    if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_hough_image: NULL argument");
+    if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t ob = (size_t)n * w * h * sizeof(uint16_t);
+    int rc = aux_reserve(p, n, w, h, ob);
+    if (rc == DH_OK) rc = stage_frames(p, frames, n, w, h);
+    if (rc == DH_OK) rc = aux_run(p, p->ws_frames, n, w, h, K, nullptr, (uint16_t *)p->aux_out, p->own_stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, p->aux_out, ob, hipMemcpyDeviceToHost, p->own_stream));
+    HIP_TRY(hipStreamSynchronize(p->own_stream));
     return DH_OK;
 }
 

@@ -153,7 +153,23 @@ struct VotesDumpArgs {
     uint32_t *count;
 };
 
+// Sibling consumers of the walk (prediction.rs:760-905): they read the per-(patch, tree) leaf ids
+// and the background flags that k_traverse writes when asked to.
+struct AuxArgs {
+    const uint16_t *frames;
+    int n_frames, w, h;
+    int step, sw, sh, lw, lh, nx, ny;
+    float k[9], kinv[9];
+    DevForest f;
+    const int32_t *leaf;     // [n][npatch][T]
+    const uint8_t *flags;    // [n][npatch] bit0 = non-background
+    uint8_t  *mask;          // predict_mask output [n][h][w]
+    uint32_t *hough32;       // 2-D Hough votes accumulated in 32 bits [n][h][w]
+};
+
 // launchers (dh_kernels.hip)
+hipError_t dh_launch_mask(const AuxArgs &a, hipStream_t s);
+hipError_t dh_launch_hough2d(const AuxArgs &a, uint16_t *out, hipStream_t s);
 hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s);
 hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, uint32_t area, void *out, hipStream_t s);
 hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s);

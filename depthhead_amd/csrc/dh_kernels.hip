@@ -1099,3 +1099,84 @@ hipError_t dh_launch_votes_dump(const VotesDumpArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_votes_dump, dim3(256), dim3(256), 0, s, a);
     return hipGetLastError();
 }
+
+// ================================================================== predict_mask / 2-D Hough votes
+// HoughPrediction::predict_mask (prediction.rs:850-905): one thread per window position.
+__device__ __forceinline__ uint8_t f64_as_u8(double v) {
+    if (v != v || v <= 0.0) return 0;
+    if (v >= 255.0) return 255;
+    return (uint8_t)v;
+}
+
+__global__ void __launch_bounds__(256) k_mask(AuxArgs a) {
+    const int frame = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x, npatch = a.nx * a.ny;
+    if (p >= npatch) return;
+    const size_t po = (size_t)frame * npatch + p;
+    if (!(a.flags[po] & 1)) return;                                   // background window (:870-878)
+    const int T = (int)a.f.n_trees;
+    double prob = 0.0;                                                // :881-882, tree order
+    for (int t = 0; t < T; ++t) prob = __dadd_rn(prob, a.f.leaf_prob[a.leaf[po * T + t]]);
+    prob = __ddiv_rn(prob, (double)T);
+    const uint8_t pv = f64_as_u8(__dmul_rn(prob, 255.0));             // :883
+    const uint32_t x = (uint32_t)(a.lw + (p % a.nx) * a.step), y = (uint32_t)(a.lh + (p / a.nx) * a.step);
+    const uint32_t step = (uint32_t)a.step, half = step / 2;
+    uint8_t *m = a.mask + (size_t)frame * a.w * a.h;
+    for (uint32_t i = 0; i < step; ++i)                               // :884-897
+        for (uint32_t j = 0; j < step; ++j) {
+            if (x + i < half || y + j < half) continue;
+            if (x + i - half >= (uint32_t)a.w || y + j - half >= (uint32_t)a.h) continue;
+            m[(size_t)(y + j - half) * a.w + (x + i - half)] = pv;
+        }
+}
+
+// Voting stage of HoughPrediction::build_hough_image (prediction.rs:760-840): one thread per
+// (window position, tree).  The u16 image of the reference wraps modulo 2^16; votes are summed in
+// 32 bits with integer atomics and narrowed afterwards, which is the same residue.
+__global__ void __launch_bounds__(256) k_hough2d(AuxArgs a) {
+    const int frame = blockIdx.y, T = (int)a.f.n_trees, npatch = a.nx * a.ny;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npatch * T) return;
+    const int p = i / T, t = i - p * T;
+    const size_t po = (size_t)frame * npatch + p;
+    if (!(a.flags[po] & 1)) return;                                   // :790-798
+    const uint32_t L = (uint32_t)a.leaf[po * T + t];
+    const double lp = a.f.leaf_prob[L];
+    if (!(lp >= 0.95)) return;                                        // :805
+    const uint32_t ob = a.f.off_begin[L], oe = a.f.off_begin[L + 1];
+    if (oe == ob) return;                                             // excluded by forest validation
+    const uint32_t val = (uint32_t)(uint16_t)(f64_as_usize(__dmul_rn(255.0, lp)) / (uint64_t)(oe - ob));   // :807-808
+    const int x = a.lw + (p % a.nx) * a.step, y = a.lh + (p / a.nx) * a.step;
+    const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
+    float p3[3];
+    to3d(a.kinv, (float)x, (float)y, (float)img[(size_t)y * a.w + x], p3);          // :777-779
+    uint32_t *out = a.hough32 + (size_t)frame * a.w * a.h;
+    for (uint32_t o = ob; o < oe; ++o) {                              // :813
+        const float *of = a.f.offsets + (size_t)o * 3;
+        float r[3];
+        matvec3(a.k, __fsub_rn(p3[0], of[0]), __fsub_rn(p3[1], of[1]), __fsub_rn(p3[2], of[2]), r);   // :814-815
+        const int32_t vx = f32_as_i32(__fdiv_rn(r[0], r[2])), vy = f32_as_i32(__fdiv_rn(r[1], r[2]));   // :816
+        if (vx < 0 || vx >= a.w || vy < 0 || vy >= a.h) continue;     // :818-831
+        atomicAdd(&out[(size_t)vy * a.w + vx], val);                  // :832
+    }
+}
+
+__global__ void __launch_bounds__(256) k_narrow_u16(const uint32_t *in, uint16_t *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint16_t)in[i];
+}
+
+hipError_t dh_launch_mask(const AuxArgs &a, hipStream_t s) {
+    const int npatch = a.nx * a.ny;
+    if (a.n_frames == 0 || npatch == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mask, dim3((npatch + 255) / 256, a.n_frames), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t dh_launch_hough2d(const AuxArgs &a, uint16_t *out, hipStream_t s) {
+    const int pairs = a.nx * a.ny * (int)a.f.n_trees;
+    if (a.n_frames == 0) return hipSuccess;
+    if (pairs > 0) hipLaunchKernelGGL(k_hough2d, dim3((pairs + 255) / 256, a.n_frames), dim3(256), 0, s, a);
+    const size_t n = (size_t)a.n_frames * a.w * a.h;
+    hipLaunchKernelGGL(k_narrow_u16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.hough32, out, n);
+    return hipGetLastError();
+}

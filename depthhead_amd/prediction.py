@@ -155,6 +155,32 @@ class HoughPrediction:
                                                 vp(midp_guess_ptr), vp(rot_guess_ptr), vp(guess_mask_ptr), vp(out_ptr),
                                                 C.c_void_p(stream) if stream else None))
 
+    # ---- sibling consumers of the walk (prediction.rs:760-905) -----------------------------
+    def predict_mask(self, img) -> np.ndarray:
+        """prediction.rs:850-905: uint8 mask [H, W] (or [n, H, W] for a batch) of per-window head
+        probability * 255."""
+        frames = np.ascontiguousarray(img, dtype=np.uint16)
+        single = frames.ndim == 2
+        if single:
+            frames = frames[None]
+        n, h, w = frames.shape
+        out = np.zeros((n, h, w), dtype=np.uint8)
+        check(self._lib.dh_predict_mask(self._ph, vp(frames), C.c_int(n), C.c_int(w), C.c_int(h), vp(out)))
+        return out[0] if single else out
+
+    def build_hough_votes(self, img, intrinsic: IntrinsicMatrix) -> np.ndarray:
+        """Voting stage of `build_hough_image` (prediction.rs:760-840): the uint16 image BEFORE
+        imageproc's gaussian_blur_f32 (:844), which is an external crate and is not applied here."""
+        frames = np.ascontiguousarray(img, dtype=np.uint16)
+        single = frames.ndim == 2
+        if single:
+            frames = frames[None]
+        n, h, w = frames.shape
+        K = np.ascontiguousarray(intrinsic.mat, dtype=np.float32).reshape(9)
+        out = np.zeros((n, h, w), dtype=np.uint16)
+        check(self._lib.dh_hough_image(self._ph, vp(frames), C.c_int(n), C.c_int(w), C.c_int(h), vp(K), vp(out)))
+        return out[0] if single else out
+
     def reserve(self, n: int, w: int, h: int) -> None:
         check(self._lib.dh_predictor_reserve(self._ph, C.c_int(n), C.c_int(w), C.c_int(h)))
 

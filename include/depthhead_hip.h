@@ -149,6 +149,22 @@ int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, int n, int 
                             const float K[9], const float *midp_guess, const double *rot_guess,
                             const uint8_t *guess_mask, dh_pose *out, void *stream);
 
+/* ---- sibling consumers of the tree walk (same kernel, different epilogue) ----
+ * HoughPrediction::predict_mask (prediction.rs:850-905): per window the mean leaf probability,
+ * as u8 = (prob * 255) painted into a stepwidth x stepwidth block; mask is n*h*w bytes. */
+int dh_predict_mask(dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask);
+int dh_predict_mask_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask,
+                           void *stream);
+/* The VOTING stage of HoughPrediction::build_hough_image (prediction.rs:760-840): every leaf with
+ * prob >= 0.95 casts (255 * prob) / n_offsets at the projected vote pixel, u16 wrapping.  out is
+ * n*h*w u16, the image the reference then passes to imageproc::filter::gaussian_blur_f32 (:844) --
+ * that external blur (and the argmax of predict_parameter_from2dhough, :343-367) is left to the
+ * caller. */
+int dh_hough_image(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                   uint16_t *out);
+int dh_hough_image_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                          uint16_t *out, void *stream);
+
 /* Allocate the workspace for batches of up to n frames of w x h. */
 int dh_predictor_reserve(dh_predictor *p, int n, int w, int h);
 

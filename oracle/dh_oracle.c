@@ -496,6 +496,85 @@ int orc_predict(const orc_forest *f, const orc_model *m, const uint16_t *img, ui
     return 0;
 }
 
+/* ------------------------------------------------------------------ predict_mask (prediction.rs:850-905) */
+static inline uint8_t f64_as_u8(double v) {
+    if (v != v || v <= 0.0) return 0;
+    if (v >= 255.0) return 255;
+    return (uint8_t)v;
+}
+
+int orc_predict_mask(const orc_forest *f, const orc_model *m, const uint16_t *img, uint32_t w, uint32_t h,
+                     int rect_mode, uint8_t *mask) {
+    uint32_t nx, ny;
+    if (!f || !img || !mask || orc_patch_grid(w, h, m, &nx, &ny) || f->n_trees == 0) return -1;
+    const uint32_t T = f->n_trees, sw = m->subimage_width, sh = m->subimage_height, step = m->stepwidth;
+    const uint32_t left_w = sw / 2, right_w = sw - left_w, left_h = sh / 2, right_h = sh - left_h;   /* :853-856 */
+    frame_view fv = {img, w, h, NULL};
+    uint64_t *sat = NULL;
+    if (rect_mode == ORC_RECT_SAT) { sat = build_sat(img, w, h); if (!sat) return -2; fv.sat = sat; }
+    const uint16_t whole[4] = {0, 0, (uint16_t)sw, (uint16_t)sh};
+    memset(mask, 0, (size_t)w * h);                                                     /* ImageBuffer::new zero-fills (:852) */
+    for (uint32_t y = left_h; y < h - right_h; y += step)                               /* :858 */
+        for (uint32_t x = left_w; x < w - right_w; x += step) {                         /* :860 */
+            uint32_t ox = x - left_w, oy = y - left_h;
+            if (!(rect_avg(&fv, ox, oy, whole) > 0.0)) continue;                        /* :870-878 */
+            double prob = 0.0;                                                          /* :881-882 */
+            for (uint32_t t = 0; t < T; ++t) prob = prob + f->leaf_prob[walk_tree(f, t, &fv, ox, oy)];
+            prob = prob / (double)T;
+            uint8_t pv = f64_as_u8(prob * 255.0);                                       /* :883 */
+            for (uint32_t i = 0; i < step; ++i)                                         /* :884 */
+                for (uint32_t j = 0; j < step; ++j) {
+                    if (x + i < step / 2 || y + j < step / 2) continue;                 /* :886 */
+                    if (x + i - step / 2 >= w || y + j - step / 2 >= h) continue;       /* :889 */
+                    mask[(size_t)(y + j - step / 2) * w + (x + i - step / 2)] = pv;     /* :892-896 */
+                }
+        }
+    free(sat);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ build_hough_image, voting stage (prediction.rs:760-840) */
+int orc_hough_image(const orc_forest *f, const orc_model *m, const uint16_t *img, uint32_t w, uint32_t h,
+                    const float K[9], int rect_mode, uint16_t *out) {
+    uint32_t nx, ny;
+    if (!f || !img || !out || !K || orc_patch_grid(w, h, m, &nx, &ny) || f->n_trees == 0) return -1;
+    const uint32_t T = f->n_trees, sw = m->subimage_width, sh = m->subimage_height, step = m->stepwidth;
+    const uint32_t left_w = sw / 2, right_w = sw - left_w, left_h = sh / 2, right_h = sh - left_h;   /* :767-770 */
+    frame_view fv = {img, w, h, NULL};
+    uint64_t *sat = NULL;
+    if (rect_mode == ORC_RECT_SAT) { sat = build_sat(img, w, h); if (!sat) return -2; fv.sat = sat; }
+    float Kinv[9];
+    inv3_f32(K, Kinv);
+    const uint16_t whole[4] = {0, 0, (uint16_t)sw, (uint16_t)sh};
+    memset(out, 0, (size_t)w * h * 2);                                                  /* :766 */
+    for (uint32_t y = left_h; y < h - right_h; y += step)                               /* :773 */
+        for (uint32_t x = left_w; x < w - right_w; x += step) {                         /* :775 */
+            uint16_t z = img[(size_t)y * w + x];                                        /* :777 */
+            float p3[3];
+            to3d(Kinv, (float)x, (float)y, (float)z, p3);                               /* :779 */
+            uint32_t ox = x - left_w, oy = y - left_h;
+            if (!(rect_avg(&fv, ox, oy, whole) > 0.0)) continue;                        /* :790-798 */
+            for (uint32_t t = 0; t < T; ++t) {                                          /* :803 */
+                int32_t L = walk_tree(f, t, &fv, ox, oy);
+                double lp = f->leaf_prob[L];
+                if (!(lp >= 0.95)) continue;                                            /* :805 */
+                uint32_t ob = f->off_begin[L], oe = f->off_begin[L + 1];
+                if (oe == ob) { free(sat); return -3; }                                 /* reference divides by zero (:807) */
+                uint16_t valtoadd = (uint16_t)(f64_as_usize(255.0 * lp) / (uint64_t)(oe - ob));   /* :807-808 */
+                for (uint32_t i = ob; i < oe; ++i) {                                    /* :813 */
+                    float np[3], p2[2];
+                    for (int k = 0; k < 3; ++k) np[k] = p3[k] - f->offsets[(size_t)i * 3 + k];     /* :814 */
+                    to2d(K, np, p2);                                                    /* :815 */
+                    int32_t vx = f32_as_i32(p2[0]), vy = f32_as_i32(p2[1]);             /* :816 */
+                    if (vx < 0 || (uint32_t)vx >= w || vy < 0 || (uint32_t)vy >= h) continue;       /* :818-831 */
+                    out[(size_t)vy * w + vx] = (uint16_t)(out[(size_t)vy * w + vx] + valtoadd);     /* :832, u16 wraps */
+                }
+            }
+        }
+    free(sat);
+    return 0;
+}
+
 int orc_predict_batch(const orc_forest *f, const orc_model *m, const uint16_t *imgs, uint32_t n,
                       uint32_t w, uint32_t h, const float K[9], const float *midp_guess,
                       const double *rot_guess, int rect_mode, int threads, orc_pose *out) {

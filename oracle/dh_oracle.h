@@ -112,6 +112,16 @@ int orc_predict_batch(const orc_forest *f, const orc_model *m, const uint16_t *i
                       uint32_t w, uint32_t h, const float K[9], const float *midp_guess,
                       const double *rot_guess, int rect_mode, int threads, orc_pose *out);
 
+/* ---- sibling consumers of the tree walk ---- */
+/* HoughPrediction::predict_mask (prediction.rs:850-905): per-patch mean leaf probability as u8,
+ * painted into a stepwidth x stepwidth block.  mask: w*h bytes, fully written. */
+int orc_predict_mask(const orc_forest *f, const orc_model *m, const uint16_t *img, uint32_t w, uint32_t h,
+                     int rect_mode, uint8_t *mask);
+/* The voting stage of HoughPrediction::build_hough_image (prediction.rs:760-840), i.e. the u16 image
+ * BEFORE imageproc's gaussian_blur_f32 (:844; external crate, not restated).  out: w*h u16. */
+int orc_hough_image(const orc_forest *f, const orc_model *m, const uint16_t *img, uint32_t w, uint32_t h,
+                    const float K[9], int rect_mode, uint16_t *out);
+
 /* ---- helpers exported for the known-answer tests ---- */
 void   orc_mat3_inv_f64(const double m[9], double out[9]);        /* meancov_estimation.rs:344-352 */
 void   orc_mat3_inv_f32(const float m[9], float out[9]);

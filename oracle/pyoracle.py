@@ -168,3 +168,28 @@ def predict_batch(forest, model, imgs: np.ndarray, K: np.ndarray, midp_guess=Non
     if rc != 0:
         raise ValueError(f"orc_predict_batch failed: {rc}")
     return out
+
+
+def predict_mask(forest, model, img: np.ndarray, rect_mode: int = RECT_SAT) -> np.ndarray:
+    """HoughPrediction::predict_mask (prediction.rs:850-905) -> uint8 [h, w]."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    fs, ms = _forest_struct(forest), _model_struct(model)
+    out = np.zeros((h, w), dtype=np.uint8)
+    rc = lib().orc_predict_mask(C.byref(fs), C.byref(ms), _p(img), C.c_uint32(w), C.c_uint32(h), C.c_int(rect_mode), _p(out))
+    if rc != 0:
+        raise ValueError(f"orc_predict_mask failed: {rc}")
+    return out
+
+
+def hough_image(forest, model, img: np.ndarray, K: np.ndarray, rect_mode: int = RECT_SAT) -> np.ndarray:
+    """Voting stage of HoughPrediction::build_hough_image (prediction.rs:760-840), before the blur."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+    fs, ms = _forest_struct(forest), _model_struct(model)
+    out = np.zeros((h, w), dtype=np.uint16)
+    rc = lib().orc_hough_image(C.byref(fs), C.byref(ms), _p(img), C.c_uint32(w), C.c_uint32(h), _p(K), C.c_int(rect_mode), _p(out))
+    if rc != 0:
+        raise ValueError(f"orc_hough_image failed: {rc}")
+    return out

@@ -358,3 +358,30 @@ def test_many_trees_scratch_fallback(hp_mod, oracle):
     model = synth.ModelParams(stepwidth=4)
     frames = synth.biwi_batch(2, 240, 200, first=70)
     _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(240, 200), full=False)
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_predict_mask_and_hough_votes(hp_mod, oracle, general):
+    """predict_mask (prediction.rs:850-905) and the voting stage of
+    build_hough_image (:760-840) reuse the walk kernel; both are byte-exact against the oracle."""
+    forest = synth.fit_forest(6, 10, synth.FOREST_SEED_BASE + 170, n_frames=12, subset=1500)
+    assert (forest.leaf_prob >= 0.95).any()
+    cases = [(320, 240, 4), (200, 160, 7), (168, 128, 1), (240, 200, 10)]
+    with general_path(general):
+        for w, h, step in cases:
+            model = synth.ModelParams(stepwidth=step)
+            frames = synth.biwi_batch(3, w, h, first=80)
+            frames[2, : h // 2] = 0                                   # half the frame background
+            K = synth.default_intrinsic(w, h)
+            with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+                masks = hp.predict_mask(frames)
+                votes = hp.build_hough_votes(frames, hp_mod.IntrinsicMatrix(K))
+                poses = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))     # the main path still works afterwards
+                one = hp.predict_mask(frames[1])
+            for i in range(3):
+                assert np.array_equal(masks[i], oracle.predict_mask(forest, model, frames[i])), (w, h, step, i)
+                assert np.array_equal(votes[i], oracle.hough_image(forest, model, frames[i], K)), (w, h, step, i)
+            assert np.array_equal(one, masks[1])
+            assert masks.max() > 0 and votes.max() > 0
+            ref = oracle.predict_batch(forest, model, frames, K)
+            assert np.array_equal(poses["mid_point"], ref["mid_point"]) and np.array_equal(poses["rotation"], ref["rotation"])
