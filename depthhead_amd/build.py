@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdepthhead_hip.so")
-SOURCES = ["dh_api.hip", "dh_kernels.hip"]
+SOURCES = ["dh_api.hip", "dh_kernels.hip", "dh_biwi.hip"]
 HEADERS = ["dh_internal.h", os.path.join("..", "..", "include", "depthhead_hip.h")]
 
 # -ffp-contract=off: no FMA contraction on host or device -- every float expression keeps the

@@ -33,6 +33,15 @@ static int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? DH_ENOMEM : DH_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// shared with dh_biwi.hip
+int dh_fail_(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 extern "C" const char *dh_last_error(void) { return g_err; }
 extern "C" int dh_version(void) { return DH_VERSION; }
 

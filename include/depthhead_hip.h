@@ -171,6 +171,16 @@ int dh_predictor_reserve(dh_predictor *p, int n, int w, int h);
 /* Number of sliding-window positions for a frame size (prediction.rs:535-548, 684-686). */
 int dh_patch_grid(const dh_params *p, int w, int h, int *nx, int *ny);
 
+/* ---- BIWI Kinect Head Pose Database formats (frame ingest, src/db_reader/biwi.rs) ----
+ * read_depth (biwi.rs:81-103): run-length coded depth `.bin` -> row-major u16.  Call with out == NULL
+ * to obtain *w, *h.  Where the reference returns an io::Error (truncated file) or panics (a run
+ * overruns the image) this returns DH_EINVAL. */
+int dh_biwi_decode_depth(const uint8_t *buf, size_t len, uint16_t *out, size_t cap_px, uint32_t *w, uint32_t *h);
+/* read_cal (biwi.rs:27-60): `depth.cal` text -> row-major 3x3 intrinsic (first three lines). */
+int dh_biwi_parse_cal(const char *text, size_t len, float K[9]);
+/* read_gt (biwi.rs:63-77): 24-byte pose file -> head position (mm), its projection, rotation (deg). */
+int dh_biwi_parse_pose(const uint8_t *buf, size_t len, const float K[9], float pos3d[3], float pos2d[2], float rot[3]);
+
 /* ---- profiling ---- */
 int dh_set_profiling(dh_predictor *p, int on); /* HIP events around each kernel, on the launch stream */
 int dh_get_timing(dh_predictor *p, dh_timing *out); /* synchronises the recorded events */
