@@ -1,0 +1,102 @@
+"""Row N1: importer for the reference's serde-JSON model.  The payload shapes (NodeParam, Rect,
+LeafParam, HoughPrediction scalars) are known from in-tree derives; stamm's own nesting is not
+verifiable offline, so the importer is schema-tolerant and these tests drive it with several
+plausible nestings of the same forest -- all must yield the same flat forest and the same poses."""
+import json
+
+import numpy as np
+import pytest
+
+from depthhead_amd import stamm_json, synth
+
+
+def _same(a, b):
+    return (a.nodes.tobytes() == b.nodes.tobytes() and np.array_equal(a.roots, b.roots) and np.array_equal(a.leaf_prob, b.leaf_prob)
+            and np.array_equal(a.off_begin, b.off_begin) and np.array_equal(a.offsets, b.offsets) and np.array_equal(a.rotations, b.rotations))
+
+
+def _canon(f):
+    """Renumber nodes / leaves in the importer's order (depth-first, first child first) via a round trip."""
+    return stamm_json.import_json(stamm_json.export_json(f, synth.ModelParams()))[0]
+
+
+def test_roundtrip_nested_layout(oracle):
+    f = synth.synth_forest(3, 6, 41)
+    p = synth.ModelParams(stepwidth=7, gaussian_sigma=6.5, meanshift_iterations=11)
+    g, q = stamm_json.import_json(stamm_json.export_json(f, p))
+    assert (q.stepwidth, q.subimage_width, q.subimage_height, q.gaussian_sigma, q.meanshift_iterations) == (7, 80, 80, 6.5, 11)
+    assert g.n_nodes == f.n_nodes and g.n_leaves == f.n_leaves and g.max_depth() == f.max_depth()
+    assert _same(g, _canon(g))                                    # importing is idempotent on its own output
+    frame = synth.biwi_like(200, 160, 77)
+    K = synth.default_intrinsic(200, 160)
+    a = oracle.predict(f, p, frame, K, taps=False)
+    b = oracle.predict(g, q, frame, K, taps=False)
+    assert np.array_equal(a.mid_point, b.mid_point) and np.array_equal(a.rotation, b.rotation)   # renumbering does not change the model
+
+
+def _retag(node, style):
+    """Rewrite the exporter's {"Inner": {param,left,right}} / {"Leaf": {...}} nesting into other shapes."""
+    if "Leaf" in node:
+        leaf = node["Leaf"]
+        return {"leaf": leaf} if style == "struct" else {"value": {"Leaf": leaf}, "left": None, "right": None} if style == "option" else leaf
+    inn = node["Inner"]
+    l, r = _retag(inn["left"], style), _retag(inn["right"], style)
+    if style == "struct":       # payload fields inlined next to the children, children keyed zero / one (reversed order)
+        return {"one": r, "zero": l, **inn["param"]}
+    if style == "option":       # struct with a tagged value and optional boxed children
+        return {"value": {"InnerNode": inn["param"]}, "left": l, "right": r}
+    return [inn["param"], l, r]  # tuple-like
+
+
+@pytest.mark.parametrize("style", ["struct", "option", "tuple"])
+def test_other_nestings_give_the_same_forest(style):
+    f = synth.synth_forest(2, 5, 43)
+    p = synth.ModelParams()
+    doc = json.loads(stamm_json.export_json(f, p))
+    doc["forest"] = {"trees": [{"tree_function": {"max_depth": 15}, "root": _retag(t["root"], style)} for t in doc["forest"]["subtrees"]]}
+    g, _ = stamm_json.import_json(json.dumps(doc))
+    assert _same(g, _canon(f))
+
+
+def test_flat_layout_and_child_convention():
+    f = synth.synth_forest(2, 4, 45)
+    p = synth.ModelParams()
+    trees = []
+    for r in f.roots:
+        arr, index = [], {}
+
+        def emit(ref):
+            if ref in index:
+                return index[ref]
+            i = len(arr)
+            index[ref] = i
+            arr.append(None)
+            if ref < 0:
+                L = ~ref
+                arr[i] = {"prob": float(f.leaf_prob[L]), "offsets": f.offsets[f.off_begin[L]:f.off_begin[L + 1]].tolist(),
+                          "rotations": f.rotations[f.rot_begin[L]:f.rot_begin[L + 1]].tolist()}
+            else:
+                nd = f.nodes[ref]
+                rect = lambda q: {"topleft": [int(q[0]), int(q[1])], "bottomright": [int(q[2]), int(q[3])]}
+                arr[i] = {"param": {"r1": rect(nd["r1"]), "r2": rect(nd["r2"]), "threshold": float(nd["threshold"])},
+                          "left": emit(int(nd["child_zero"])), "right": emit(int(nd["child_one"]))}
+            return i
+
+        trees.append({"root": emit(int(r)), "nodes": arr})
+    doc = {"stepwidth": 4, "subimage_width": 80, "subimage_height": 80, "gaussian_sigma": 8.0, "meanshift_iterations": 20,
+           "forest": {"subtrees": trees}}
+    g, _ = stamm_json.import_json(json.dumps(doc))
+    assert _same(g, _canon(f))
+    # the unverifiable part is explicit: with Binar::One -> left every node's children swap
+    h, _ = stamm_json.import_json(json.dumps(doc), one_child="left")
+    assert np.array_equal(h.nodes["child_zero"], g.nodes["child_one"]) and np.array_equal(h.nodes["child_one"], g.nodes["child_zero"])
+    assert not np.array_equal(h.nodes["child_zero"], g.nodes["child_zero"])
+    assert h.n_nodes == g.n_nodes and np.array_equal(h.leaf_prob, g.leaf_prob)
+
+
+def test_rejects_other_documents():
+    with pytest.raises(ValueError):
+        stamm_json.import_json('{"stepwidth": 4}')
+    with pytest.raises(ValueError):
+        stamm_json.import_json(json.dumps({"stepwidth": 4, "subimage_width": 80, "subimage_height": 80, "gaussian_sigma": 8.0,
+                                           "meanshift_iterations": 20, "forest": {"subtrees": []}}))
