@@ -44,6 +44,7 @@ EXPORTS = [
     "dh_predict_batch", "dh_predict_batch_device", "dh_predictor_reserve", "dh_patch_grid",
     "dh_predict_mask", "dh_predict_mask_device", "dh_hough_image", "dh_hough_image_device",
     "dh_biwi_decode_depth", "dh_biwi_parse_cal", "dh_biwi_parse_pose",
+    "dh_graph_capture", "dh_graph_launch", "dh_graph_destroy",
     "dh_set_profiling", "dh_get_timing", "dh_debug_enable", "dh_debug_leaf_indices", "dh_debug_patch_flags",
     "dh_debug_grids", "dh_debug_guesses", "dh_debug_votes", "dh_debug_meanshift", "dh_debug_hit_counts",
 ]

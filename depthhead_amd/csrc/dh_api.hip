@@ -243,6 +243,9 @@ struct dh_predictor {
     void *aux_out = nullptr;
     size_t aux_out_bytes = 0;
     int aux_cap = 0;
+    // captured batch (hipGraph)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
     // taps
     bool debug = false;
     int32_t *dbg_leaf = nullptr;
@@ -323,6 +326,8 @@ static void free_workspace(dh_predictor *p) {
 extern "C" int dh_predictor_destroy(dh_predictor *p) {
     if (!p) return DH_OK;
     (void)hipSetDevice(p->device);
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
     free_workspace(p);
     for (void *q : p->forest_allocs) (void)hipFree(q);
@@ -386,6 +391,7 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     auto hipstep = [&](hipError_t e, const char *what) {
         if (rc == DH_OK && e != hipSuccess) rc = fail(DH_EHIP, "%s: %s", what, hipGetErrorString(e));
     };
+    if (rc == DH_OK) hipstep(dh_kernels_init(), "hipFuncSetAttribute");
     if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking), "hipStreamCreate");
     if (rc == DH_OK) hipstep(dh_launch_leaf_prepare(d, p->own_stream), "k_leaf_prepare launch");
     if (rc == DH_OK) hipstep(hipStreamSynchronize(p->own_stream), "k_leaf_prepare");
@@ -650,6 +656,45 @@ extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, 
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, p->ws_poses, (size_t)n * sizeof(dh_pose), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return DH_OK;
+}
+
+// ------------------------------------------------------------------ hipGraph capture of one batch
+// For launch-bound use (small frames / single frames, BASELINE config 5): the memset + three kernel
+// launches of one dh_predict_batch_device call are captured once and replayed with one host call.
+extern "C" int dh_graph_destroy(dh_predictor *p) {
+    if (!p) return fail(DH_EINVAL, "NULL predictor");
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    p->graph_exec = nullptr; p->graph = nullptr;
+    return DH_OK;
+}
+
+extern "C" int dh_graph_capture(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                                const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out) {
+    if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_graph_capture: NULL argument");
+    if (n <= 0) return fail(DH_EINVAL, "batch size must be positive");
+    if (p->debug || p->profiling) return fail(DH_ESTATE, "taps / profiling cannot be captured");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = reserve(p, n, w, h);          // every allocation happens before the capture starts
+    if (rc) return rc;
+    dh_graph_destroy(p);
+    HIP_TRY(hipStreamSynchronize(p->own_stream));
+    HIP_TRY(hipStreamBeginCapture(p->own_stream, hipStreamCaptureModeThreadLocal));
+    rc = dh_predict_batch_device(p, frames, n, w, h, K, midp_guess, rot_guess, guess_mask, out, p->own_stream);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(p->own_stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return fail(DH_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    p->graph = g;
+    HIP_TRY(hipGraphInstantiate(&p->graph_exec, p->graph, nullptr, nullptr, 0));
+    return DH_OK;
+}
+
+extern "C" int dh_graph_launch(dh_predictor *p, void *stream) {
+    if (!p) return fail(DH_EINVAL, "NULL predictor");
+    if (!p->graph_exec) return fail(DH_ESTATE, "no captured batch (dh_graph_capture)");
+    HIP_TRY(hipGraphLaunch(p->graph_exec, (hipStream_t)stream));
     return DH_OK;
 }
 

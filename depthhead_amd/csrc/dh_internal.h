@@ -170,6 +170,7 @@ struct AuxArgs {
 // launchers (dh_kernels.hip)
 hipError_t dh_launch_mask(const AuxArgs &a, hipStream_t s);
 hipError_t dh_launch_hough2d(const AuxArgs &a, uint16_t *out, hipStream_t s);
+hipError_t dh_kernels_init();
 hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s);
 hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, uint32_t area, void *out, hipStream_t s);
 hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s);

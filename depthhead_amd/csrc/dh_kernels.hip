@@ -693,7 +693,9 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     }
 }
 
-hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s) {
+// Raise the dynamic-LDS limit of the walk kernel (once per process; not allowed during stream capture,
+// so dh_predictor_create calls it).
+hipError_t dh_kernels_init() {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -701,6 +703,10 @@ hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    return hipSuccess;
+}
+
+hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s) {
     int frames8 = (a.n_frames + 7) / 8 * 8;
     int grid = frames8 * a.tiles_x * a.tiles_y;
     if (grid == 0) return hipSuccess;

@@ -181,6 +181,17 @@ class HoughPrediction:
         check(self._lib.dh_hough_image(self._ph, vp(frames), C.c_int(n), C.c_int(w), C.c_int(h), vp(K), vp(out)))
         return out[0] if single else out
 
+    def graph_capture(self, frames_ptr: int, n: int, w: int, h: int, intrinsic: IntrinsicMatrix, out_ptr: int,
+                      midp_guess_ptr: int | None = None, rot_guess_ptr: int | None = None,
+                      guess_mask_ptr: int | None = None) -> None:
+        """Capture one device-resident batch into a hipGraph (pointers are baked in)."""
+        K = np.ascontiguousarray(intrinsic.mat, dtype=np.float32).reshape(9)
+        check(self._lib.dh_graph_capture(self._ph, vp(frames_ptr), C.c_int(n), C.c_int(w), C.c_int(h), vp(K),
+                                         vp(midp_guess_ptr), vp(rot_guess_ptr), vp(guess_mask_ptr), vp(out_ptr)))
+
+    def graph_launch(self, stream: int = 0) -> None:
+        check(self._lib.dh_graph_launch(self._ph, C.c_void_p(stream) if stream else None))
+
     def reserve(self, n: int, w: int, h: int) -> None:
         check(self._lib.dh_predictor_reserve(self._ph, C.c_int(n), C.c_int(w), C.c_int(h)))
 

@@ -165,6 +165,14 @@ int dh_hough_image(dh_predictor *p, const uint16_t *frames, int n, int w, int h,
 int dh_hough_image_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                           uint16_t *out, void *stream);
 
+/* hipGraph path for launch-bound use (single frames, small frames): capture ONE
+ * dh_predict_batch_device call -- device pointers, sizes and K are baked in -- then replay it with one
+ * host call per batch; new inputs are written into the same buffers between replays. */
+int dh_graph_capture(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                     const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out);
+int dh_graph_launch(dh_predictor *p, void *stream);
+int dh_graph_destroy(dh_predictor *p);
+
 /* Allocate the workspace for batches of up to n frames of w x h. */
 int dh_predictor_reserve(dh_predictor *p, int n, int w, int h);
 

@@ -385,3 +385,27 @@ def test_predict_mask_and_hough_votes(hp_mod, oracle, general):
             assert masks.max() > 0 and votes.max() > 0
             ref = oracle.predict_batch(forest, model, frames, K)
             assert np.array_equal(poses["mid_point"], ref["mid_point"]) and np.array_equal(poses["rotation"], ref["rotation"])
+
+
+def test_hipgraph_replay(hp_mod, oracle):
+    """BASELINE config 5's launch-bound regime: one captured batch replayed on new frame contents."""
+    torch = pytest.importorskip("torch")
+    from depthhead_amd._lib import POSE_DTYPE
+    forest = synth.synth_forest(6, 10, synth.FOREST_SEED_BASE + 8)
+    model = synth.ModelParams(stepwidth=1)
+    w, h, n = 320, 240, 2
+    K = synth.default_intrinsic(w, h)
+    dev = torch.device("cuda:0")
+    a, b = synth.biwi_batch(n, w, h, first=90), synth.biwi_batch(n, w, h, first=95)
+    fr = torch.from_numpy(a.view(np.int16)).to(dev)
+    out = torch.zeros(n * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.graph_capture(fr.data_ptr(), n, w, h, hp_mod.IntrinsicMatrix(K), out.data_ptr())
+        st = torch.cuda.current_stream(dev)
+        for frames in (a, b, a):
+            fr.copy_(torch.from_numpy(frames.view(np.int16)))
+            hp.graph_launch(st.cuda_stream)
+            st.synchronize()
+            poses = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)
+            ref = oracle.predict_batch(forest, model, frames, K)
+            assert np.array_equal(poses["mid_point"], ref["mid_point"]) and np.array_equal(poses["rotation"], ref["rotation"])
