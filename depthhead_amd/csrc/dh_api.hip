@@ -593,43 +593,61 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     return DH_OK;
 }
 
+// Largest number of frames whose hit records are resident at once (64 B x window positions x trees
+// per frame: 9 MB per frame at BASELINE config 2).  Larger batches are walked in slices on the same
+// stream, reusing the workspace.
+static int max_resident_frames() {
+    static int v = 0;
+    if (!v) {
+        v = 512;
+        if (const char *e = getenv("DH_MAX_RESIDENT_FRAMES")) v = std::max(1, atoi(e));
+    }
+    return v;
+}
+
 extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                                        const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
                                        dh_pose *out, void *stream_) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_batch_device: NULL argument");
     if (n == 0) return DH_OK;
-    int rc = reserve(p, n, w, h);
+    if (n < 0) return fail(DH_EINVAL, "negative batch size");
+    const int slice = p->debug ? n : std::min(n, max_resident_frames());   // the taps index the whole batch
+    int rc = reserve(p, slice, w, h);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream_;
-    HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3) * sizeof(uint32_t), s));
     float kinv[9];
     mat3_inv_f32(K, kinv);   // cached in a RefCell by the reference (types.rs:436-441)
-
-    // The walk kernel is throughput-bound, the vote / mean-shift kernels are latency-bound with few
-    // waves: the batch is cut into sub-batches that run on forked streams (joined back into the
-    // caller's stream before returning), so the mean shift of one sub-batch hides under the tree
-    // walks of the next.  Taps and per-kernel profiling need one ordered pass.
-    int chunks = p->chunks;
-    if (p->profiling || p->debug || n < 2 * DH_MIN_CHUNK_FRAMES) chunks = 1;
-    chunks = std::min(chunks, n / DH_MIN_CHUNK_FRAMES);
-    if (chunks <= 1) {
-        rc = enqueue_range(p, frames, 0, n, w, h, K, kinv, midp_guess, rot_guess, guess_mask, out, s, p->profiling);
-        if (rc) return rc;
-    } else {
-        HIP_TRY(hipEventRecord(p->ev_fork, s));
-        for (int c = 0; c < chunks; ++c) {
-            const int f0 = (int)((long long)n * c / chunks), f1 = (int)((long long)n * (c + 1) / chunks);
-            hipStream_t cs = c == 0 ? s : p->aux_stream[c - 1];
-            if (c > 0) HIP_TRY(hipStreamWaitEvent(cs, p->ev_fork, 0));
-            rc = enqueue_range(p, frames, f0, f1 - f0, w, h, K, kinv, midp_guess, rot_guess, guess_mask, out, cs, false);
+    for (int f0 = 0; f0 < n; f0 += slice) {
+        const int m = std::min(slice, n - f0);
+        HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3) * sizeof(uint32_t), s));
+        const uint16_t *fr = frames + (size_t)f0 * w * h;
+        const float *mg = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
+        const double *rg = rot_guess ? rot_guess + (size_t)f0 * 3 : nullptr;
+        const uint8_t *gm = guess_mask ? guess_mask + f0 : nullptr;
+        // Optional forked sub-batches (DH_CHUNKS > 1): measured on MI355X to give no overlap gain
+        // (1.016 vs 1.022 ms per 256 frames), so one ordered pass is the default.
+        int chunks = p->chunks;
+        if (p->profiling || p->debug || m < 2 * DH_MIN_CHUNK_FRAMES) chunks = 1;
+        chunks = std::min(chunks, m / DH_MIN_CHUNK_FRAMES);
+        if (chunks <= 1) {
+            rc = enqueue_range(p, fr, 0, m, w, h, K, kinv, mg, rg, gm, out + f0, s, p->profiling);
             if (rc) return rc;
-            if (c > 0) {
-                HIP_TRY(hipEventRecord(p->ev_join[c - 1], cs));
-                HIP_TRY(hipStreamWaitEvent(s, p->ev_join[c - 1], 0));
+        } else {
+            HIP_TRY(hipEventRecord(p->ev_fork, s));
+            for (int c = 0; c < chunks; ++c) {
+                const int c0 = (int)((long long)m * c / chunks), c1 = (int)((long long)m * (c + 1) / chunks);
+                hipStream_t cs = c == 0 ? s : p->aux_stream[c - 1];
+                if (c > 0) HIP_TRY(hipStreamWaitEvent(cs, p->ev_fork, 0));
+                rc = enqueue_range(p, fr, c0, c1 - c0, w, h, K, kinv, mg, rg, gm, out + f0, cs, false);
+                if (rc) return rc;
+                if (c > 0) {
+                    HIP_TRY(hipEventRecord(p->ev_join[c - 1], cs));
+                    HIP_TRY(hipStreamWaitEvent(s, p->ev_join[c - 1], 0));
+                }
             }
         }
     }
-    p->last_n = n;
+    p->last_n = std::min(n, slice);   // the taps describe the last resident slice
     p->last_frames = frames;
     p->dbg_valid = p->debug;
     return DH_OK;
@@ -642,20 +660,24 @@ extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, 
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_batch: NULL argument");
     if (n == 0) return DH_OK;
     if (n < 0) return fail(DH_EINVAL, "negative batch size");
-    int rc = reserve(p, n, w, h);
-    if (rc) return rc;
     HIP_TRY(hipSetDevice(p->device));
-    rc = stage_frames(p, frames, n, w, h);
-    if (rc) return rc;
+    const int slice = p->debug ? n : std::min(n, max_resident_frames());
     hipStream_t s = p->own_stream;
-    if (midp_guess) HIP_TRY(hipMemcpyAsync(p->ws_midp, midp_guess, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
-    if (rot_guess) HIP_TRY(hipMemcpyAsync(p->ws_rot, rot_guess, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    if (guess_mask) HIP_TRY(hipMemcpyAsync(p->ws_mask, guess_mask, (size_t)n, hipMemcpyHostToDevice, s));
-    rc = dh_predict_batch_device(p, p->ws_frames, n, w, h, K, midp_guess ? p->ws_midp : nullptr,
-                                 rot_guess ? p->ws_rot : nullptr, guess_mask ? p->ws_mask : nullptr, p->ws_poses, s);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, p->ws_poses, (size_t)n * sizeof(dh_pose), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    for (int f0 = 0; f0 < n; f0 += slice) {      // host batches are staged slice by slice
+        const int m = std::min(slice, n - f0);
+        int rc = reserve(p, m, w, h);
+        if (rc) return rc;
+        rc = stage_frames(p, frames + (size_t)f0 * w * h, m, w, h);
+        if (rc) return rc;
+        if (midp_guess) HIP_TRY(hipMemcpyAsync(p->ws_midp, midp_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+        if (rot_guess) HIP_TRY(hipMemcpyAsync(p->ws_rot, rot_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+        if (guess_mask) HIP_TRY(hipMemcpyAsync(p->ws_mask, guess_mask + f0, (size_t)m, hipMemcpyHostToDevice, s));
+        rc = dh_predict_batch_device(p, p->ws_frames, m, w, h, K, midp_guess ? p->ws_midp : nullptr,
+                                     rot_guess ? p->ws_rot : nullptr, guess_mask ? p->ws_mask : nullptr, p->ws_poses, s);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out + f0, p->ws_poses, (size_t)m * sizeof(dh_pose), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     return DH_OK;
 }
 
@@ -676,7 +698,7 @@ extern "C" int dh_graph_capture(dh_predictor *p, const uint16_t *frames, int n, 
     if (n <= 0) return fail(DH_EINVAL, "batch size must be positive");
     if (p->debug || p->profiling) return fail(DH_ESTATE, "taps / profiling cannot be captured");
     HIP_TRY(hipSetDevice(p->device));
-    int rc = reserve(p, n, w, h);          // every allocation happens before the capture starts
+    int rc = reserve(p, std::min(n, max_resident_frames()), w, h);   // every allocation happens before the capture starts
     if (rc) return rc;
     dh_graph_destroy(p);
     HIP_TRY(hipStreamSynchronize(p->own_stream));
@@ -758,18 +780,28 @@ static int aux_run(dh_predictor *p, const uint16_t *frames, int n, int w, int h,
 extern "C" int dh_predict_mask_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask, void *stream) {
     if (!p || !frames || !mask) return fail(DH_EINVAL, "dh_predict_mask_device: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
-    int rc = aux_reserve(p, n, w, h, 0);
-    if (rc) return rc;
-    return aux_run(p, frames, n, w, h, nullptr, mask, nullptr, (hipStream_t)stream);
+    const int slice = std::min(n, max_resident_frames());
+    for (int f0 = 0; f0 < n; f0 += slice) {
+        const int m = std::min(slice, n - f0);
+        int rc = aux_reserve(p, m, w, h, 0);
+        if (rc == DH_OK) rc = aux_run(p, frames + (size_t)f0 * w * h, m, w, h, nullptr, mask + (size_t)f0 * w * h, nullptr, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return DH_OK;
 }
 
 extern "C" int dh_hough_image_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                                      uint16_t *out, void *stream) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_hough_image_device: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
-    int rc = aux_reserve(p, n, w, h, 0);
-    if (rc) return rc;
-    return aux_run(p, frames, n, w, h, K, nullptr, out, (hipStream_t)stream);
+    const int slice = std::min(n, max_resident_frames());
+    for (int f0 = 0; f0 < n; f0 += slice) {
+        const int m = std::min(slice, n - f0);
+        int rc = aux_reserve(p, m, w, h, 0);
+        if (rc == DH_OK) rc = aux_run(p, frames + (size_t)f0 * w * h, m, w, h, K, nullptr, out + (size_t)f0 * w * h, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return DH_OK;
 }
 
 static int stage_frames(dh_predictor *p, const uint16_t *frames, int n, int w, int h) {
@@ -778,7 +810,7 @@ static int stage_frames(dh_predictor *p, const uint16_t *frames, int n, int w, i
         HIP_TRY(hipStreamSynchronize(p->own_stream));
         if (p->ws_frames) (void)hipFree(p->ws_frames);
         p->ws_frames = nullptr; p->ws_frames_bytes = 0;
-        size_t want = (size_t)p->cap_frames * w * h * sizeof(uint16_t);
+        size_t want = fbytes;
         int rc = dev_alloc(p, &p->ws_frames, want / sizeof(uint16_t));
         if (rc) return rc;
         p->ws_frames_bytes = want;
@@ -791,13 +823,17 @@ extern "C" int dh_predict_mask(dh_predictor *p, const uint16_t *frames, int n, i
     if (!p || !frames || !mask) return fail(DH_EINVAL, "dh_predict_mask: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     HIP_TRY(hipSetDevice(p->device));
-    const size_t ob = (size_t)n * w * h;
-    int rc = aux_reserve(p, n, w, h, ob);
-    if (rc == DH_OK) rc = stage_frames(p, frames, n, w, h);
-    if (rc == DH_OK) rc = aux_run(p, p->ws_frames, n, w, h, nullptr, (uint8_t *)p->aux_out, nullptr, p->own_stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(mask, p->aux_out, ob, hipMemcpyDeviceToHost, p->own_stream));
-    HIP_TRY(hipStreamSynchronize(p->own_stream));
+    const int slice = std::min(n, max_resident_frames());
+    for (int f0 = 0; f0 < n; f0 += slice) {
+        const int m = std::min(slice, n - f0);
+        const size_t ob = (size_t)m * w * h;
+        int rc = aux_reserve(p, m, w, h, ob);
+        if (rc == DH_OK) rc = stage_frames(p, frames + (size_t)f0 * w * h, m, w, h);
+        if (rc == DH_OK) rc = aux_run(p, p->ws_frames, m, w, h, nullptr, (uint8_t *)p->aux_out, nullptr, p->own_stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(mask + (size_t)f0 * w * h, p->aux_out, ob, hipMemcpyDeviceToHost, p->own_stream));
+        HIP_TRY(hipStreamSynchronize(p->own_stream));
+    }
     return DH_OK;
 }
 
@@ -805,13 +841,17 @@ extern "C" int dh_hough_image(dh_predictor *p, const uint16_t *frames, int n, in
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_hough_image: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     HIP_TRY(hipSetDevice(p->device));
-    const size_t ob = (size_t)n * w * h * sizeof(uint16_t);
-    int rc = aux_reserve(p, n, w, h, ob);
-    if (rc == DH_OK) rc = stage_frames(p, frames, n, w, h);
-    if (rc == DH_OK) rc = aux_run(p, p->ws_frames, n, w, h, K, nullptr, (uint16_t *)p->aux_out, p->own_stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, p->aux_out, ob, hipMemcpyDeviceToHost, p->own_stream));
-    HIP_TRY(hipStreamSynchronize(p->own_stream));
+    const int slice = std::min(n, max_resident_frames());
+    for (int f0 = 0; f0 < n; f0 += slice) {
+        const int m = std::min(slice, n - f0);
+        const size_t ob = (size_t)m * w * h * sizeof(uint16_t);
+        int rc = aux_reserve(p, m, w, h, ob);
+        if (rc == DH_OK) rc = stage_frames(p, frames + (size_t)f0 * w * h, m, w, h);
+        if (rc == DH_OK) rc = aux_run(p, p->ws_frames, m, w, h, K, nullptr, (uint16_t *)p->aux_out, p->own_stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out + (size_t)f0 * w * h, p->aux_out, ob, hipMemcpyDeviceToHost, p->own_stream));
+        HIP_TRY(hipStreamSynchronize(p->own_stream));
+    }
     return DH_OK;
 }
 

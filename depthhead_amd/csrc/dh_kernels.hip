@@ -748,24 +748,34 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         if (fc & LF_OFF) {
             const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
             uint32_t last = 0xFFFFFFFFu, acc = 0;      // a leaf's votes mostly share a cell: one atomic per run
-            for (uint32_t o = ob; o < oe; ++o) {
-                const float *of = a.f.offsets + (size_t)o * 3;
-                float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // :647
-                if (nz < 0.0f) continue;                                                  // :650
-                float r[3];
-                matvec3(a.k, nx, ny, nz, r);                                              // types.rs:425
-                float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
-                float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;               // :662
-                float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;               // :663
-                // x2 in [0, w-1]: the usize arithmetic of :671-674 fits 32 bits
-                uint32_t gx = (uint32_t)f32_as_usize(x2) * DH_GRID / (uint32_t)a.w;        // :671-672
-                uint32_t gy = (uint32_t)f32_as_usize(y2) * DH_GRID / (uint32_t)a.h;
-                const uint32_t idx = gy * DH_GRID + gx;
-                if (idx != last) {
-                    if (acc) atomicAdd(&pos[last], acc);                                  // :675
-                    last = idx; acc = 0;
+            for (uint32_t o0 = ob; o0 < oe; o0 += 4) {   // 4 votes in flight: their loads do not depend on each other
+                float ox[4], oy[4], oz[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t o = min(o0 + j, oe - 1);
+                    const float *of = a.f.offsets + (size_t)o * 3;
+                    ox[j] = of[0]; oy[j] = of[1]; oz[j] = of[2];
                 }
-                acc += v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (o0 + j >= oe) break;
+                    float nx = __fsub_rn(rec.x, ox[j]), ny = __fsub_rn(rec.y, oy[j]), nz = __fsub_rn(rec.z, oz[j]); // :647
+                    if (nz < 0.0f) continue;                                              // :650
+                    float r[3];
+                    matvec3(a.k, nx, ny, nz, r);                                          // types.rs:425
+                    float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
+                    float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;           // :662
+                    float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;           // :663
+                    // x2 in [0, w-1]: the usize arithmetic of :671-674 fits 32 bits
+                    uint32_t gx = (uint32_t)f32_as_usize(x2) * DH_GRID / (uint32_t)a.w;    // :671-672
+                    uint32_t gy = (uint32_t)f32_as_usize(y2) * DH_GRID / (uint32_t)a.h;
+                    const uint32_t idx = gy * DH_GRID + gx;
+                    if (idx != last) {
+                        if (acc) atomicAdd(&pos[last], acc);                              // :675
+                        last = idx; acc = 0;
+                    }
+                    acc += v;
+                }
             }
             if (acc) atomicAdd(&pos[last], acc);
         }

@@ -409,3 +409,33 @@ def test_hipgraph_replay(hp_mod, oracle):
             poses = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)
             ref = oracle.predict_batch(forest, model, frames, K)
             assert np.array_equal(poses["mid_point"], ref["mid_point"]) and np.array_equal(poses["rotation"], ref["rotation"])
+
+
+def test_batches_larger_than_the_resident_slice(hp_mod, oracle, monkeypatch):
+    """Batches beyond DH_MAX_RESIDENT_FRAMES are walked slice by slice on the same workspace."""
+    import depthhead_amd._lib as L
+    forest = synth.synth_forest(5, 8, synth.FOREST_SEED_BASE + 180)
+    model = synth.ModelParams(stepwidth=6)
+    w, h, n = 200, 160, 11
+    frames = synth.biwi_batch(n, w, h, first=130)
+    K = synth.default_intrinsic(w, h)
+    ref = oracle.predict_batch(forest, model, frames, K)
+    # the limit is read once per process: drive the C entry point of a child process with a small slice
+    import subprocess, sys, os, json, tempfile
+    np.save(os.path.join(tempfile.gettempdir(), "dh_slice_frames.npy"), frames)
+    code = (
+        "import numpy as np, os, tempfile, json\n"
+        "from depthhead_amd import synth\n"
+        "from depthhead_amd.prediction import HoughPrediction, IntrinsicMatrix\n"
+        "frames = np.load(os.path.join(tempfile.gettempdir(), 'dh_slice_frames.npy'))\n"
+        f"forest = synth.synth_forest(5, 8, {synth.FOREST_SEED_BASE + 180}); model = synth.ModelParams(stepwidth=6)\n"
+        f"K = synth.default_intrinsic({w}, {h})\n"
+        "with HoughPrediction(forest, model) as hp:\n"
+        "    p = hp.predict_batch(frames, IntrinsicMatrix(K)); m = hp.predict_mask(frames)\n"
+        "print(json.dumps({'mid': p['mid_point'].tolist(), 'rot': p['rotation'].tolist(), 'mask': int(m.astype(np.int64).sum())}))\n")
+    env = dict(os.environ, DH_MAX_RESIDENT_FRAMES="4")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert np.array_equal(np.array(got["mid"], dtype=np.float32), ref["mid_point"]) and np.array_equal(np.array(got["rot"]), ref["rotation"])
+    assert got["mask"] == sum(int(oracle.predict_mask(forest, model, f).astype(np.int64).sum()) for f in frames)
