@@ -203,6 +203,18 @@ extern "C" int dh_patch_grid(const dh_params *p, int w, int h, int *nx, int *ny)
     return patch_grid(*p, w, h, nx, ny);
 }
 
+// Entry points run on the predictor's device and leave the caller's current device as they found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 // ------------------------------------------------------------------ predictor
 #define DH_MAX_CHUNKS 8
 #define DH_MIN_CHUNK_FRAMES 16
@@ -611,6 +623,8 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_batch_device: NULL argument");
     if (n == 0) return DH_OK;
     if (n < 0) return fail(DH_EINVAL, "negative batch size");
+    DeviceGuard guard(p->device);
+    if (!guard.ok) return fail(DH_EHIP, "cannot select device %d", p->device);
     const int slice = p->debug ? n : std::min(n, max_resident_frames());   // the taps index the whole batch
     int rc = reserve(p, slice, w, h);
     if (rc) return rc;
@@ -780,6 +794,8 @@ static int aux_run(dh_predictor *p, const uint16_t *frames, int n, int w, int h,
 extern "C" int dh_predict_mask_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask, void *stream) {
     if (!p || !frames || !mask) return fail(DH_EINVAL, "dh_predict_mask_device: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
+    DeviceGuard guard(p->device);
+    if (!guard.ok) return fail(DH_EHIP, "cannot select device %d", p->device);
     const int slice = std::min(n, max_resident_frames());
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
@@ -794,6 +810,8 @@ extern "C" int dh_hough_image_device(dh_predictor *p, const uint16_t *frames, in
                                      uint16_t *out, void *stream) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_hough_image_device: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
+    DeviceGuard guard(p->device);
+    if (!guard.ok) return fail(DH_EHIP, "cannot select device %d", p->device);
     const int slice = std::min(n, max_resident_frames());
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);

@@ -439,3 +439,38 @@ def test_batches_larger_than_the_resident_slice(hp_mod, oracle, monkeypatch):
     got = json.loads(out.stdout.strip().splitlines()[-1])
     assert np.array_equal(np.array(got["mid"], dtype=np.float32), ref["mid_point"]) and np.array_equal(np.array(got["rot"]), ref["rotation"])
     assert got["mask"] == sum(int(oracle.predict_mask(forest, model, f).astype(np.int64).sum()) for f in frames)
+
+
+def test_randomized_differential(hp_mod, oracle):
+    """40 seeded random configurations (frame size, patch size, stride, forest shape, rectangle mix,
+    sigma, iterations, intrinsics, guesses): HIP path == oracle on every pose and on leaf indices."""
+    rs = np.random.RandomState(20260104)
+    for case in range(40):
+        sw, sh = int(rs.randint(24, 97)), int(rs.randint(24, 97))
+        w, h = sw + int(rs.randint(0, 140)), sh + int(rs.randint(0, 110))
+        step = int(rs.randint(1, 12))
+        trees, depth = int(rs.randint(1, 13)), int(rs.randint(1, 11))
+        mixed = rs.rand() < 0.4
+        forest = synth.synth_forest(trees, depth, 5000 + case, patch=(sw, sh), rect_scale=float(rs.uniform(0.08, 0.5)),
+                                    rect_scale_max=float(rs.uniform(0.5, 0.9)) if mixed else None,
+                                    full_depth=int(rs.randint(0, depth + 1)), p_split=float(rs.uniform(0.4, 0.95)))
+        model = synth.ModelParams(stepwidth=step, subimage_width=sw, subimage_height=sh,
+                                  gaussian_sigma=float(rs.uniform(0.5, 30.0)), meanshift_iterations=int(rs.randint(0, 25)))
+        n = int(rs.randint(1, 4))
+        frames = np.stack([synth.biwi_like(max(w, 96), max(h, 96), 9000 + case * 7 + i)[:h, :w] for i in range(n)]).copy()
+        if rs.rand() < 0.3:
+            frames[0] = (rs.rand(h, w) < 0.02) * rs.randint(1, 65536, (h, w))        # sparse speckle, full u16 range
+        f = float(rs.uniform(200, 900))
+        K = np.array([[f, rs.uniform(-2, 2), w / 2 + rs.uniform(-20, 20)], [0, f * rs.uniform(0.9, 1.1), h / 2], [0, 0, 1]], dtype=np.float32)
+        midp = rs.uniform(-300, 1500, (n, 3)).astype(np.float32) if rs.rand() < 0.3 else None
+        rot = rs.uniform(-1.5, 1.5, (n, 3)) if rs.rand() < 0.3 else None
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            hp.debug_enable(True)
+            poses = hp.predict_batch(frames.astype(np.uint16), hp_mod.IntrinsicMatrix(K), midp, rot)
+            leaf = hp.debug_leaf_indices(n, w, h)
+        for i in range(n):
+            ref = oracle.predict(forest, model, frames[i], K, None if midp is None else midp[i], None if rot is None else rot[i])
+            tag = f"case {case}: {w}x{h} patch {sw}x{sh} step {step} trees {trees} depth {depth} mixed {mixed} frame {i}"
+            assert np.array_equal(leaf[i], ref.leaf_idx), tag
+            assert np.array_equal(poses["mid_point"][i], ref.mid_point), (tag, poses["mid_point"][i], ref.mid_point)
+            assert np.array_equal(poses["rotation"][i], ref.rotation), (tag, poses["rotation"][i], ref.rotation)
