@@ -721,10 +721,13 @@ hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream
 // (exact, order-free, wrapping like the reference's release-mode u32 `+=`).
 #define VOTE_THREADS 512
 #define VOTE_SLICES 8
+#define VOTE_TAB 2048
 
+template <bool TAB>
 __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
     __shared__ uint32_t pos[DH_POSGRID];
     __shared__ uint32_t rot[DH_GRID3];
+    __shared__ uint8_t gxt[VOTE_TAB], gyt[VOTE_TAB];   // pixel -> guess-grid column / row: x * 20 / w (:671-674) without a division per vote
     const int frame = blockIdx.y, tid = threadIdx.x;
     uint32_t n = a.hit_count[frame];
     if (n > a.hits_cap) n = a.hits_cap;
@@ -733,49 +736,48 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
     if (h0 >= h1) return;
     for (int i = tid; i < DH_POSGRID; i += VOTE_THREADS) pos[i] = 0;
     for (int i = tid; i < DH_GRID3; i += VOTE_THREADS) rot[i] = 0;
+    if (TAB) {
+        for (int i = tid; i < a.w; i += VOTE_THREADS) gxt[i] = (uint8_t)((uint32_t)i * DH_GRID / (uint32_t)a.w);
+        for (int i = tid; i < a.h; i += VOTE_THREADS) gyt[i] = (uint8_t)((uint32_t)i * DH_GRID / (uint32_t)a.h);
+    }
     __syncthreads();
     const HitRec *hits = a.hits + (size_t)frame * a.hits_cap;
     const HitBox *box = a.hit_box + (size_t)frame * a.hits_cap;
     const HitRot *hr = a.hit_rot + (size_t)frame * a.hits_cap;
     const float wm1 = (float)(a.w - 1), hm1 = (float)(a.h - 1);
-    for (uint32_t i = h0 + tid; i < h1; i += VOTE_THREADS) {
+    // 8 lanes share one hit record: lane `sub` takes the leaf's votes sub, sub+8, ... so the chain of
+    // dependent offset loads per lane is n_votes/8 long and all lanes of the workgroup stay busy
+    const uint32_t sub = tid & 7u;
+    for (uint32_t i = h0 + (tid >> 3); i < h1; i += VOTE_THREADS / 8) {
         const float4 rec = *(const float4 *)(hits + i);
         const int4 b1 = ((const int4 *)(box + i))[1];
         const uint4 rr = *(const uint4 *)(hr + i);
         const uint32_t v = (uint32_t)b1.z, fc = (uint32_t)b1.w;
         if (fc & LF_ROT)
-            for (uint32_t r = rr.z; r < rr.z + (rr.w >> 16); ++r) atomicAdd(&rot[a.f.rot_rough[r]], v * a.f.rough_mult[r]);   // :636
+            for (uint32_t r = rr.z + sub; r < rr.z + (rr.w >> 16); r += 8) atomicAdd(&rot[a.f.rot_rough[r]], v * a.f.rough_mult[r]);   // :636
         if (fc & LF_OFF) {
             const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
-            uint32_t last = 0xFFFFFFFFu, acc = 0;      // a leaf's votes mostly share a cell: one atomic per run
-            for (uint32_t o0 = ob; o0 < oe; o0 += 4) {   // 4 votes in flight: their loads do not depend on each other
-                float ox[4], oy[4], oz[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t o = min(o0 + j, oe - 1);
-                    const float *of = a.f.offsets + (size_t)o * 3;
-                    ox[j] = of[0]; oy[j] = of[1]; oz[j] = of[2];
+            uint32_t last = 0xFFFFFFFFu, acc = 0;      // neighbouring votes mostly share a cell: one atomic per run
+            for (uint32_t o = ob + sub; o < oe; o += 8) {
+                const float *of = a.f.offsets + (size_t)o * 3;
+                float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // :647
+                if (nz < 0.0f) continue;                                                  // :650
+                float r[3];
+                matvec3(a.k, nx, ny, nz, r);                                              // types.rs:425
+                float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
+                float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;               // :662
+                float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;               // :663
+                // x2 in [0, w-1]: the usize arithmetic of :671-674 fits 32 bits
+                // x2 in [0, w-1] and never NaN after the clamps: `as usize` is a plain truncation
+                const uint32_t xi = (uint32_t)x2, yi = (uint32_t)y2;
+                const uint32_t gx = TAB ? gxt[xi] : xi * DH_GRID / (uint32_t)a.w;          // :671-672
+                const uint32_t gy = TAB ? gyt[yi] : yi * DH_GRID / (uint32_t)a.h;
+                const uint32_t idx = gy * DH_GRID + gx;
+                if (idx != last) {
+                    if (acc) atomicAdd(&pos[last], acc);                                  // :675
+                    last = idx; acc = 0;
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (o0 + j >= oe) break;
-                    float nx = __fsub_rn(rec.x, ox[j]), ny = __fsub_rn(rec.y, oy[j]), nz = __fsub_rn(rec.z, oz[j]); // :647
-                    if (nz < 0.0f) continue;                                              // :650
-                    float r[3];
-                    matvec3(a.k, nx, ny, nz, r);                                          // types.rs:425
-                    float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
-                    float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;           // :662
-                    float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;           // :663
-                    // x2 in [0, w-1]: the usize arithmetic of :671-674 fits 32 bits
-                    uint32_t gx = (uint32_t)f32_as_usize(x2) * DH_GRID / (uint32_t)a.w;    // :671-672
-                    uint32_t gy = (uint32_t)f32_as_usize(y2) * DH_GRID / (uint32_t)a.h;
-                    const uint32_t idx = gy * DH_GRID + gx;
-                    if (idx != last) {
-                        if (acc) atomicAdd(&pos[last], acc);                              // :675
-                        last = idx; acc = 0;
-                    }
-                    acc += v;
-                }
+                acc += v;
             }
             if (acc) atomicAdd(&pos[last], acc);
         }
@@ -788,7 +790,8 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
 
 hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
     if (a.n_frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_vote, dim3(VOTE_SLICES, a.n_frames), dim3(VOTE_THREADS), 0, s, a);
+    if (a.w <= VOTE_TAB && a.h <= VOTE_TAB) hipLaunchKernelGGL(k_vote<true>, dim3(VOTE_SLICES, a.n_frames), dim3(VOTE_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_vote<false>, dim3(VOTE_SLICES, a.n_frames), dim3(VOTE_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
