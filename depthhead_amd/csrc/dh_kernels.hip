@@ -496,74 +496,74 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             __syncthreads();
         }
     }
-    // ---- (UNI) node cache: the box image uses rows [0, bh); the rh rows below it are free.  They
-    // take the first NC nodes of every tree (breadth-first order: its top levels), so the first
-    // levels of each walk read 16 bytes from LDS instead of chasing global memory.
-    int NC = 0;
-    const uint4 *ncache = nullptr;
-    if (UNI) {
-        const int st = ((fh + 1 - a.rh) * ss + 3) & ~3;              // first free word, 16-byte aligned
-        NC = min(((fh + 1) * ss - st) / (4 * T), 127);              // 4 words per NodeU
-        uint4 *nc = (uint4 *)(sat + st);
-        ncache = nc;
-        const NodeU *nodes_u = (const NodeU *)a.nodes_u;
-        for (int i = tid; i < NC * T; i += TRAV_THREADS) {
-            const int t = i / NC, k = i - t * NC;
-            const int root = a.f.roots[t];
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (root >= 0 && (uint32_t)(root + k) < a.f.n_nodes) v = *(const uint4 *)(nodes_u + root + k);
-            nc[i] = v;
-        }
-        __syncthreads();
-    }
-
     STAMP(4)
     // ---- phase 3: root->leaf walks.  Work item k = (tree k / n_active, active slot k % n_active),
     // lane = k mod 1024: the lanes of a wave walk the SAME tree for NEIGHBOURING windows (4 px apart),
     // which see almost the same pixels, so they mostly follow the same path: node fetches collapse
     // to a few addresses per wave and walks end within a level or two of each other.
-    // (A ballot-compacted refill of finished lanes was built and measured: it lengthens this phase
-    // by 25-50 % because it breaks exactly that coherence -- DESIGN.md section 4.)  Trees are
-    // validated acyclic on the host, so every walk ends.
+    // (Measured and rejected on MI355X, DESIGN.md section 4: a ballot-compacted refill of finished
+    // lanes lengthens this phase by 25-50 % because it breaks exactly that coherence; an LDS cache
+    // of the top tree levels and a persistent launch with per-XCD tile queues gain nothing.)
+    // Trees are validated acyclic on the host, so every walk ends.
     const int total = n_active * T;
-    {
+    if (UNI) {
+        // Two walks per lane, advanced in lock step: their node fetches and box-sum reads are
+        // independent, so each lane keeps two dependent-load chains in flight.
         const NodeU *nodes_u = (const NodeU *)a.nodes_u;
+        for (int k = tid; k < total; k += 2 * TRAV_THREADS) {
+            const int kb = k + TRAV_THREADS;
+            const bool hasb = kb < total;
+            const int ta = k / n_active, sa = k - ta * n_active;
+            const int tb = hasb ? kb / n_active : ta, sb = hasb ? kb - tb * n_active : sa;
+            const int pa = (int)active[sa], pb = (int)active[sb];
+            const int pya = pa / cx, pxa = pa - pya * cx, pyb = pb / cx, pxb = pb - pyb * cx;
+            const uint32_t *spa = sat + pya * a.step * ss + pxa * a.step;
+            const uint32_t *spb = sat + pyb * a.step * ss + pxb * a.step;
+            int ca = a.f.roots[ta], cb = hasb ? a.f.roots[tb] : -1;
+            while (ca >= 0 || cb >= 0) {
+                const int ia = ca >= 0 ? ca : 0, ib = cb >= 0 ? cb : 0;      // a finished walk re-reads node 0 harmlessly
+                const uint4 na = *(const uint4 *)(nodes_u + ia), nb = *(const uint4 *)(nodes_u + ib);
+                const uint32_t a1 = spa[na.x & 0x3fffu], a2 = spa[(na.x >> 14) & 0x3fffu];
+                const uint32_t b1 = spb[nb.x & 0x3fffu], b2 = spb[(nb.x >> 14) & 0x3fffu];
+                // HoughTreeFunctions::binarize (houghforest.rs:185-193): two box sums, integer test
+                const int32_t da = (int32_t)a1 - (int32_t)a2, db = (int32_t)b1 - (int32_t)b2;
+                bool onea = da > (int32_t)na.y, oneb = db > (int32_t)nb.y;
+                const uint32_t amba = na.x >> 28, ambb = nb.x >> 28;
+                if (ca >= 0 && amba && onea && da <= (int32_t)na.y + (int32_t)amba) {
+                    // inside the band the integer test cannot decide: the reference's own arithmetic
+                    const double thr = a.f.nodes[ca].threshold, c = (double)a.area;
+                    onea = __dsub_rn(__ddiv_rn((double)a1, c), __ddiv_rn((double)a2, c)) > thr;   // types.rs:338
+                }
+                if (cb >= 0 && ambb && oneb && db <= (int32_t)nb.y + (int32_t)ambb) {
+                    const double thr = a.f.nodes[cb].threshold, c = (double)a.area;
+                    oneb = __dsub_rn(__ddiv_rn((double)b1, c), __ddiv_rn((double)b2, c)) > thr;
+                }
+                if (ca >= 0) ca = onea ? (int)na.w : (int)na.z;
+                if (cb >= 0) cb = oneb ? (int)nb.w : (int)nb.z;
+            }
+            leaf[pa * T + ta] = ~ca;
+            if (hasb) leaf[pb * T + tb] = ~cb;
+        }
+    } else {
         for (int k = tid; k < total; k += TRAV_THREADS) {
             const int t = k / n_active, slot = k - t * n_active;
             const int p = (int)active[slot];
             const int pyi = p / cx, pxi = p - pyi * cx;
             const uint32_t *sp = sat + pyi * a.step * ss + pxi * a.step;
             int cur = a.f.roots[t];
-            const int croot = cur, cbase = t * NC;
             while (cur >= 0) {
-                if (UNI) {
-                    // HoughTreeFunctions::binarize (houghforest.rs:185-193): two box sums, integer test
-                    const uint32_t rel = (uint32_t)(cur - croot);
-                    const uint4 nd = rel < (uint32_t)NC ? ncache[cbase + rel] : *(const uint4 *)(nodes_u + cur);
-                    const uint32_t s1 = sp[nd.x & 0x3fffu], s2 = sp[(nd.x >> 14) & 0x3fffu];
-                    const int32_t d = (int32_t)s1 - (int32_t)s2, ilo = (int32_t)nd.y;
-                    bool one = d > ilo;
-                    const uint32_t amb = nd.x >> 28;
-                    if (amb && one && d <= ilo + (int32_t)amb) {
-                        // inside the band the integer test cannot decide: the reference's own arithmetic
-                        const double thr = a.f.nodes[cur].threshold, c = (double)a.area;
-                        one = __dsub_rn(__ddiv_rn((double)s1, c), __ddiv_rn((double)s2, c)) > thr;   // types.rs:338
-                    }
-                    cur = one ? (int)nd.w : (int)nd.z;
-                } else {
-                    // general rectangles: 8 SAT corners, IEEE f64 means (types.rs:317-339)
-                    const uint4 *np = (const uint4 *)(a.f.nodes + cur);
-                    const uint4 n0 = np[0], n1 = np[1];
-                    const int ax0 = n0.x & 0xffff, ay0 = n0.x >> 16, ax1 = n0.y & 0xffff, ay1 = n0.y >> 16;
-                    const int bx0 = n0.z & 0xffff, by0 = n0.z >> 16, bx1 = n0.w & 0xffff, by1 = n0.w >> 16;
-                    const double thr = __hiloint2double((int)n1.y, (int)n1.x);
-                    const uint32_t s1 = sp[ay1 * ss + ax1] - sp[ay0 * ss + ax1] - sp[ay1 * ss + ax0] + sp[ay0 * ss + ax0];
-                    const uint32_t s2 = sp[by1 * ss + bx1] - sp[by0 * ss + bx1] - sp[by1 * ss + bx0] + sp[by0 * ss + bx0];
-                    const uint32_t c1 = (uint32_t)((ax1 - ax0) * (ay1 - ay0)), c2 = (uint32_t)((bx1 - bx0) * (by1 - by0));
-                    const double a1 = c1 ? __ddiv_rn((double)s1, (double)c1) : 0.0;   // types.rs:335-338
-                    const double a2 = c2 ? __ddiv_rn((double)s2, (double)c2) : 0.0;
-                    cur = (__dsub_rn(a1, a2) > thr) ? (int)n1.w : (int)n1.z;
-                }
+                // general rectangles: 8 SAT corners, IEEE f64 means (types.rs:317-339)
+                const uint4 *np = (const uint4 *)(a.f.nodes + cur);
+                const uint4 n0 = np[0], n1 = np[1];
+                const int ax0 = n0.x & 0xffff, ay0 = n0.x >> 16, ax1 = n0.y & 0xffff, ay1 = n0.y >> 16;
+                const int bx0 = n0.z & 0xffff, by0 = n0.z >> 16, bx1 = n0.w & 0xffff, by1 = n0.w >> 16;
+                const double thr = __hiloint2double((int)n1.y, (int)n1.x);
+                const uint32_t s1 = sp[ay1 * ss + ax1] - sp[ay0 * ss + ax1] - sp[ay1 * ss + ax0] + sp[ay0 * ss + ax0];
+                const uint32_t s2 = sp[by1 * ss + bx1] - sp[by0 * ss + bx1] - sp[by1 * ss + bx0] + sp[by0 * ss + bx0];
+                const uint32_t c1 = (uint32_t)((ax1 - ax0) * (ay1 - ay0)), c2 = (uint32_t)((bx1 - bx0) * (by1 - by0));
+                const double a1 = c1 ? __ddiv_rn((double)s1, (double)c1) : 0.0;   // types.rs:335-338
+                const double a2 = c2 ? __ddiv_rn((double)s2, (double)c2) : 0.0;
+                cur = (__dsub_rn(a1, a2) > thr) ? (int)n1.w : (int)n1.z;
             }
             leaf[p * T + t] = ~cur;
         }
