@@ -124,7 +124,9 @@ int dh_forest_info(const dh_forest *f, uint32_t *n_trees, uint32_t *n_nodes, uin
 
 /* Upload the forest to `device`, precompute the per-leaf vote tables on the GPU and build the
  * mean-shift kernel table (get_or_build_kernel, prediction.rs:310-317).  Rejects (DH_EFOREST) a
- * split rectangle that leaves the patch and (DH_ESIZE) a patch whose pixel sum can exceed 2^32. */
+ * split rectangle that leaves the patch and (DH_ESIZE) a patch whose pixel sum can exceed 2^32.
+ * One window's summed-area table must also fit the 160 KB LDS of a CU: the first batch / reserve call
+ * refuses (DH_ESIZE) patches beyond about 195 x 195 (the reference's only trainer uses 80 x 80). */
 int dh_predictor_create(const dh_forest *f, const dh_params *p, int device, dh_predictor **out);
 int dh_predictor_destroy(dh_predictor *p);
 /* HoughPrediction::update_sigma / sigma (prediction.rs:320-331): no-op for val <= 0 or unchanged. */

@@ -474,3 +474,26 @@ def test_randomized_differential(hp_mod, oracle):
             assert np.array_equal(leaf[i], ref.leaf_idx), tag
             assert np.array_equal(poses["mid_point"][i], ref.mid_point), (tag, poses["mid_point"][i], ref.mid_point)
             assert np.array_equal(poses["rotation"][i], ref.rotation), (tag, poses["rotation"][i], ref.rotation)
+
+
+@pytest.mark.parametrize("sw,sh,w,h,step", [(250, 16, 640, 64, 16), (16, 250, 80, 480, 9), (190, 190, 300, 280, 5), (8, 8, 64, 48, 1)])
+def test_extreme_patch_shapes(hp_mod, oracle, sw, sh, w, h, step):
+    """Very wide / very tall / near-maximal and tiny patches: tile geometry, segment counts and LDS
+    carve-up at their edges.  (One window's summed-area table must fit the 160 KB LDS: patches beyond
+    about 195x195 are refused with DH_ESIZE -- the reference's only trainer uses 80x80.)"""
+    for mixed in (False, True):
+        forest = synth.synth_forest(4, 7, 777 + sw + sh, patch=(sw, sh), rect_scale=0.25, rect_scale_max=0.7 if mixed else None)
+        model = synth.ModelParams(stepwidth=step, subimage_width=sw, subimage_height=sh)
+        frames = np.stack([synth.biwi_like(max(w, 96), max(h, 96), 4242 + i)[:h, :w] for i in range(2)]).copy()
+        _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), full=False)
+
+
+def test_patch_too_large_for_lds_is_refused(hp_mod):
+    from depthhead_amd._lib import DepthheadError
+    forest = synth.synth_forest(2, 3, 5, patch=(255, 255))
+    model = synth.ModelParams(stepwidth=5, subimage_width=255, subimage_height=255)
+    frames = np.zeros((1, 280, 300), dtype=np.uint16)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        with pytest.raises(DepthheadError) as ei:
+            hp.predict_batch(frames, hp_mod.IntrinsicMatrix(synth.default_intrinsic(300, 280)))
+        assert ei.value.code == -5 and "LDS" in str(ei.value)
