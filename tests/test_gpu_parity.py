@@ -497,3 +497,20 @@ def test_patch_too_large_for_lds_is_refused(hp_mod):
         with pytest.raises(DepthheadError) as ei:
             hp.predict_batch(frames, hp_mod.IntrinsicMatrix(synth.default_intrinsic(300, 280)))
         assert ei.value.code == -5 and "LDS" in str(ei.value)
+
+
+def test_fitted_forest_config2(hp_mod, oracle):
+    """The bench's own model (trainer-sized forest fitted to synthetic subjects: coherent votes,
+    40 votes per leaf, mean shifts that move) on BASELINE config 2's geometry."""
+    forest = synth.fit_forest(10, 15, synth.FOREST_SEED_BASE + 2, n_frames=16, subset=2500)
+    model = synth.ModelParams(stepwidth=4)
+    frames = synth.biwi_batch(4, 640, 480, first=200)
+    K = synth.default_intrinsic()
+    _check_frames(hp_mod, oracle, forest, model, frames, K)
+    big = synth.biwi_batch(24, 640, 480, first=300)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        poses = hp.predict_batch(big, hp_mod.IntrinsicMatrix(K))
+    ref = oracle.predict_batch(forest, model, big, K)
+    assert np.array_equal(poses["mid_point"], ref["mid_point"]) and np.array_equal(poses["rotation"], ref["rotation"])
+    moved = sum(int(not np.array_equal(r, ref["rotation"][0])) for r in ref["rotation"])
+    assert moved > 0                                          # not one constant answer
