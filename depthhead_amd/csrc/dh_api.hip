@@ -217,6 +217,8 @@ struct DeviceGuard {
 
 // ------------------------------------------------------------------ predictor
 #define DH_MAX_CHUNKS 8
+#define DH_LEAF_HIST_MAX 16384   // per-frame leaf histogram for the rotation gather (64 KB per frame at most); larger forests
+                                 // rarely hit a leaf twice per frame and walk the hit records instead (measured: 35 k leaves is a loss)
 #define DH_MIN_CHUNK_FRAMES 16
 
 struct dh_predictor {
@@ -242,6 +244,7 @@ struct dh_predictor {
     HitRec *hits = nullptr;
     HitBox *hit_box = nullptr;
     HitRot *hit_rot = nullptr;
+    uint32_t *leaf_hits = nullptr;   // [cap][n_leaves] rotation-vote histogram, only for forests of <= DH_LEAF_HIST_MAX leaves
     uint32_t hits_cap = 0;
     uint32_t *counters = nullptr;    // [n] hit_count | [n][400] pos_grid | [n][8000] rot_grid (one memset)
     dh_pose *ws_poses = nullptr;
@@ -323,10 +326,11 @@ static int build_kernel_table(dh_predictor *p) {
 }
 
 static void free_workspace(dh_predictor *p) {
-    void *ptrs[] = {p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
+    void *ptrs[] = {p->leaf_hits, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
                     p->dbg_flags, p->dbg_guess, p->dbg_trace, p->dbg_steps, p->dbg_votes, p->dbg_vcount};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    p->leaf_hits = nullptr;
     p->aux_leaf = nullptr; p->aux_flags = nullptr; p->aux_u32 = nullptr; p->aux_out = nullptr; p->aux_out_bytes = 0; p->aux_cap = 0;
     p->ws_frames = nullptr; p->hits = nullptr; p->hit_box = nullptr; p->hit_rot = nullptr; p->counters = nullptr; p->ws_poses = nullptr; p->ws_midp = nullptr;
     p->ws_rot = nullptr; p->ws_mask = nullptr; p->dbg_leaf = nullptr; p->dbg_flags = nullptr; p->dbg_guess = nullptr;
@@ -496,6 +500,7 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     STEP(dev_alloc(p, &p->hits, (size_t)cap * hits_cap));
     STEP(dev_alloc(p, &p->hit_box, (size_t)cap * hits_cap));
     STEP(dev_alloc(p, &p->hit_rot, (size_t)cap * hits_cap));
+    if (p->n_leaves <= DH_LEAF_HIST_MAX && !getenv("DH_NO_LEAF_HIST")) STEP(dev_alloc(p, &p->leaf_hits, (size_t)cap * p->n_leaves));
     STEP(dev_alloc(p, &p->counters, (size_t)cap * (1 + DH_POSGRID + DH_GRID3)));
     STEP(dev_alloc(p, &p->ws_poses, cap));
     STEP(dev_alloc(p, &p->ws_midp, (size_t)cap * 3));
@@ -570,6 +575,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.f = p->dev;
         ta.hits = p->hits + hoff; ta.hit_box = p->hit_box + hoff; ta.hit_rot = p->hit_rot + hoff;
         ta.hit_count = hit_count; ta.hits_cap = p->hits_cap;
+        ta.leaf_hits = (p->leaf_hits && !traverse_only) ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
         ta.dbg_leaf = leaf_out ? leaf_out : p->debug ? p->dbg_leaf + (size_t)f0 * g.npatch * p->n_trees : nullptr;
         ta.dbg_flags = flags_out ? flags_out : p->debug ? p->dbg_flags + (size_t)f0 * g.npatch : nullptr;
         HIP_TRY(dh_launch_traverse(ta, g.lds, s));
@@ -592,6 +598,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         memcpy(ca.kinv, kinv, 9 * sizeof(float));
         ca.f = p->dev; ca.hits = p->hits + hoff; ca.hit_box = p->hit_box + hoff; ca.hit_rot = p->hit_rot + hoff;
         ca.hit_count = hit_count; ca.hits_cap = p->hits_cap;
+        ca.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
         ca.pos_grid = pos_grid; ca.rot_grid = rot_grid; ca.kern_ord = p->kern_ord;
         ca.iterations = p->params.meanshift_iterations;
         ca.midp_guess = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
@@ -634,6 +641,7 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
         HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3) * sizeof(uint32_t), s));
+        if (p->leaf_hits) HIP_TRY(hipMemsetAsync(p->leaf_hits, 0, (size_t)m * p->n_leaves * sizeof(uint32_t), s));
         const uint16_t *fr = frames + (size_t)f0 * w * h;
         const float *mg = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
         const double *rg = rot_guess ? rot_guess + (size_t)f0 * 3 : nullptr;

@@ -100,6 +100,7 @@ struct TraverseArgs {
     HitRot   *hit_rot;
     uint32_t *hit_count;    // [n_frames]
     uint32_t  hits_cap;     // records per frame
+    uint32_t *leaf_hits;    // nullable [n_frames][n_leaves]: how often each leaf cast rotation votes (zeroed per batch)
     int32_t  *dbg_leaf;     // nullable [n][npatch][T]
     uint8_t  *dbg_flags;    // nullable [n][npatch]
 };
@@ -127,6 +128,7 @@ struct ClusterArgs {
     const HitRot   *hit_rot;
     const uint32_t *hit_count;
     uint32_t  hits_cap;
+    const uint32_t *leaf_hits; // nullable [n_frames][n_leaves], see TraverseArgs
     const uint32_t *pos_grid;
     const uint32_t *rot_grid;
     const float    *kern_ord;  // 8000 floats, index (dx*20+dy)*20+dz = summation order (meanshift.rs:344-346)

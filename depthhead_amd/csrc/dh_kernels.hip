@@ -637,6 +637,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
                                                  f32_as_i32(__fsub_rn(q2, mx2)), f32_as_i32(__fsub_rn(q0, mn0)));
             ((int4 *)(dbox + o))[1] = make_int4(f32_as_i32(__fsub_rn(q1, mn1)), f32_as_i32(__fsub_rn(q2, mn2)), (int)t1.z, (int)t1.w);
             *(uint4 *)(drot + o) = make_uint4(t2v.y, t2v.z, t2v.w, t3.x);                           // rlo, rhi, rb, n_rot
+            if (a.leaf_hits && (lf & LF_ROT)) atomicAdd(&a.leaf_hits[(size_t)frame * a.f.n_leaves + lid], 1u);
         }
         STAMP(6)
         return;
@@ -686,6 +687,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
                                                          f32_as_i32(__fsub_rn(q2, tp.omax[2])), f32_as_i32(__fsub_rn(q0, tp.omin[0])));
                     ((int4 *)(dbox + o))[1] = make_int4(f32_as_i32(__fsub_rn(q1, tp.omin[1])), f32_as_i32(__fsub_rn(q2, tp.omin[2])), (int)tp.v, (int)tp.fc);
                     *(uint4 *)(drot + o) = make_uint4(tp.rlo, tp.rhi, tp.rb, tp.n_rot);
+                    if (a.leaf_hits && (tp.fc & LF_ROT)) atomicAdd(&a.leaf_hits[(size_t)frame * a.f.n_leaves + lid], 1u);
                 }
                 o++;
             }
@@ -946,6 +948,36 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                             uint32_t dy = (uint32_t)f32_as_i32(ny) - (uint32_t)org[1];
                             uint32_t dz = (uint32_t)f32_as_i32(__fdiv_rn(nz, (float)DH_ZSCALEFACTOR)) - (uint32_t)org[2];
                             if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], v);
+                        }
+                    }
+                }
+            } else if (a.leaf_hits) {
+                // Rotation votes depend only on the leaf (prediction.rs:601-636): the accumulator is
+                // sum over leaves of (times the leaf voted) x (its distinct cells), so the gather walks
+                // the leaves that voted at all instead of every hit -- u32 wrap-around makes
+                // hits * v * mult the same residue as that many separate adds.
+                const uint32_t *lh = a.leaf_hits + (size_t)frame * a.f.n_leaves;
+                for (uint32_t l0 = 0; l0 < a.f.n_leaves; l0 += CL_THREADS * 4) {
+                    uint32_t c[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const uint32_t l = l0 + j * CL_THREADS + tid; c[j] = l < a.f.n_leaves ? lh[l] : 0u; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!c[j]) continue;
+                        const uint4 *tp = (const uint4 *)(a.f.tpl + (l0 + j * CL_THREADS + tid));
+                        const uint4 t1 = tp[1], t2 = tp[2], t3 = tp[3];
+                        const uint32_t bl = t2.y, bh = t2.z;
+                        if (bl == 0xFFFFFFFFu) continue;
+                        if (!range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG)) continue;
+                        if (!range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG)) continue;
+                        if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG)) continue;
+                        const uint32_t v = c[j] * t1.z;
+                        for (uint32_t q = t2.w; q < t2.w + (t3.x & 0xffffu); ++q) {
+                            const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                   // prediction.rs:635
+                            uint32_t dx = (b & 255u) - (uint32_t)org[0];
+                            uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
+                            uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
+                            if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
                         }
                     }
                 }
