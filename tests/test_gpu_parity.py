@@ -514,3 +514,39 @@ def test_fitted_forest_config2(hp_mod, oracle):
     assert np.array_equal(poses["mid_point"], ref["mid_point"]) and np.array_equal(poses["rotation"], ref["rotation"])
     moved = sum(int(not np.array_equal(r, ref["rotation"][0])) for r in ref["rotation"])
     assert moved > 0                                          # not one constant answer
+
+
+def test_error_behaviour_on_device(hp_mod, hip_lib):
+    """Status codes instead of panics: taps before a batch, undersized tap buffers, NULL arguments,
+    empty batches, a frame narrower than the patch, a rectangle that leaves the patch."""
+    import ctypes as C
+    from depthhead_amd import _lib
+    from depthhead_amd._lib import DepthheadError
+    forest = synth.synth_forest(3, 5, 31)
+    model = synth.ModelParams(stepwidth=4)
+    K = hp_mod.IntrinsicMatrix(synth.default_intrinsic(160, 120))
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        with pytest.raises(DepthheadError) as ei:
+            hp.debug_grids(1)                                   # no batch yet
+        assert ei.value.code == -6
+        assert hp.predict_batch(np.zeros((0, 120, 160), dtype=np.uint16), K).shape == (0,)   # empty batch is fine
+        with pytest.raises(DepthheadError) as ei:
+            hp.predict_batch(np.zeros((1, 60, 160), dtype=np.uint16), K)        # frame shorter than the 80-px patch
+        assert ei.value.code == -5 and "smaller than" in str(ei.value)
+        frames = synth.biwi_batch(2, 160, 120)
+        hp.predict_batch(frames, K)
+        with pytest.raises(DepthheadError) as ei:
+            hp.debug_leaf_indices(2, 160, 120)                  # taps were not enabled for that batch
+        assert ei.value.code == -6
+        hp.debug_enable(True)
+        hp.predict_batch(frames, K)
+        small = np.zeros(3, dtype=np.int32)
+        assert hip_lib.dh_debug_leaf_indices(hp._ph, small.ctypes.data_as(C.c_void_p), C.c_size_t(3)) == -1
+        assert hip_lib.dh_predict_batch(hp._ph, None, 1, 160, 120, None, None, None, None, None) == -1
+        assert hip_lib.dh_graph_launch(hp._ph, None) == -6      # nothing captured
+        cnt = C.c_size_t()
+        assert hip_lib.dh_debug_votes(hp._ph, 5, 0, None, C.c_size_t(0), C.byref(cnt)) == -1   # frame out of range
+    wide = synth.synth_forest(2, 3, 32, patch=(100, 100))       # rectangles reach x = 100
+    with pytest.raises(DepthheadError) as ei:
+        hp_mod.HoughPrediction(wide, synth.ModelParams())       # 80x80 patch
+    assert ei.value.code == -2 and "leaves the" in str(ei.value)
