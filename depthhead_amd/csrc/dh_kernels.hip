@@ -724,6 +724,7 @@ hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream
 #define VOTE_THREADS 512
 #define VOTE_SLICES 8
 #define VOTE_TAB 2048
+#define VOTE_ILP 6               // offset votes a lane keeps in flight (8 lanes x 6 = a 48-vote leaf in one round)
 
 template <bool TAB>
 __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
@@ -760,26 +761,35 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         if (fc & LF_OFF) {
             const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
             uint32_t last = 0xFFFFFFFFu, acc = 0;      // neighbouring votes mostly share a cell: one atomic per run
-            for (uint32_t o = ob + sub; o < oe; o += 8) {
-                const float *of = a.f.offsets + (size_t)o * 3;
-                float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // :647
-                if (nz < 0.0f) continue;                                                  // :650
-                float r[3];
-                matvec3(a.k, nx, ny, nz, r);                                              // types.rs:425
-                float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
-                float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;               // :662
-                float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;               // :663
-                // x2 in [0, w-1]: the usize arithmetic of :671-674 fits 32 bits
-                // x2 in [0, w-1] and never NaN after the clamps: `as usize` is a plain truncation
-                const uint32_t xi = (uint32_t)x2, yi = (uint32_t)y2;
-                const uint32_t gx = TAB ? gxt[xi] : xi * DH_GRID / (uint32_t)a.w;          // :671-672
-                const uint32_t gy = TAB ? gyt[yi] : yi * DH_GRID / (uint32_t)a.h;
-                const uint32_t idx = gy * DH_GRID + gx;
-                if (idx != last) {
-                    if (acc) atomicAdd(&pos[last], acc);                                  // :675
-                    last = idx; acc = 0;
+            for (uint32_t o0 = ob + sub; o0 < oe; o0 += 8 * VOTE_ILP) {   // the lane's next VOTE_ILP votes: loads first
+                float ox[VOTE_ILP], oy[VOTE_ILP], oz[VOTE_ILP];
+#pragma unroll
+                for (int j = 0; j < VOTE_ILP; ++j) {
+                    const uint32_t o = min(o0 + 8u * j, oe - 1);
+                    const float *of = a.f.offsets + (size_t)o * 3;
+                    ox[j] = of[0]; oy[j] = of[1]; oz[j] = of[2];
                 }
-                acc += v;
+#pragma unroll
+                for (int j = 0; j < VOTE_ILP; ++j) {
+                    if (o0 + 8u * j >= oe) break;
+                    float nx = __fsub_rn(rec.x, ox[j]), ny = __fsub_rn(rec.y, oy[j]), nz = __fsub_rn(rec.z, oz[j]); // :647
+                    if (nz < 0.0f) continue;                                              // :650
+                    float r[3];
+                    matvec3(a.k, nx, ny, nz, r);                                          // types.rs:425
+                    float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
+                    float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;           // :662
+                    float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;           // :663
+                    // x2 in [0, w-1] and never NaN after the clamps: `as usize` is a plain truncation
+                    const uint32_t xi = (uint32_t)x2, yi = (uint32_t)y2;
+                    const uint32_t gx = TAB ? gxt[xi] : xi * DH_GRID / (uint32_t)a.w;      // :671-672
+                    const uint32_t gy = TAB ? gyt[yi] : yi * DH_GRID / (uint32_t)a.h;
+                    const uint32_t idx = gy * DH_GRID + gx;
+                    if (idx != last) {
+                        if (acc) atomicAdd(&pos[last], acc);                              // :675
+                        last = idx; acc = 0;
+                    }
+                    acc += v;
+                }
             }
             if (acc) atomicAdd(&pos[last], acc);
         }
