@@ -981,13 +981,20 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                         if (!range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG)) continue;
                         if (!range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG)) continue;
                         if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG)) continue;
-                        const uint32_t v = c[j] * t1.z;
-                        for (uint32_t q = t2.w; q < t2.w + (t3.x & 0xffffu); ++q) {
-                            const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                   // prediction.rs:635
-                            uint32_t dx = (b & 255u) - (uint32_t)org[0];
-                            uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
-                            uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
-                            if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
+                        const uint32_t v = c[j] * t1.z, q1 = t2.w + (t3.x & 0xffffu);
+                        for (uint32_t q0 = t2.w; q0 < q1; q0 += 4) {   // 4 cells in flight: the loads do not depend on each other
+                            uint32_t bb[4], mm[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { const uint32_t qi = min(q0 + k, q1 - 1); bb[k] = a.f.rot_bin[qi]; mm[k] = a.f.rot_mult[qi]; }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                if (q0 + k >= q1) break;
+                                const uint32_t b = bb[k], vm = v * mm[k];                                                  // prediction.rs:635
+                                uint32_t dx = (b & 255u) - (uint32_t)org[0];
+                                uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
+                                uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
+                                if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
+                            }
                         }
                     }
                 }
