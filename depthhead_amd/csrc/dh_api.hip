@@ -181,7 +181,8 @@ extern "C" int dh_forest_info(const dh_forest *f, uint32_t *n_trees, uint32_t *n
 struct Geom {
     int w = 0, h = 0, nx = 0, ny = 0, npatch = 0;
     int px = 0, py = 0, tiles_x = 0, tiles_y = 0, ss_max = 0, ss_row = 0;
-    bool uniform = false;
+    bool uniform = false;       // uniform-rectangle path: k_boxsum feeds k_traverse<true>
+    int box_pitch = 0, box_rows = 0, box_tx = 0, box_ty = 0;
     size_t lds = 0;
 };
 
@@ -244,6 +245,7 @@ struct dh_predictor {
     HitRec *hits = nullptr;
     HitBox *hit_box = nullptr;
     HitRot *hit_rot = nullptr;
+    uint32_t *box = nullptr;         // [cap][box_rows][box_pitch] rectangle-sum images (uniform path)
     uint32_t *leaf_hits = nullptr;   // [cap][n_leaves] rotation-vote histogram, only for forests of <= DH_LEAF_HIST_MAX leaves
     uint32_t hits_cap = 0;
     uint32_t *counters = nullptr;    // [n] hit_count | [n][400] pos_grid | [n][8000] rot_grid (one memset)
@@ -276,7 +278,7 @@ struct dh_predictor {
     const uint16_t *last_frames = nullptr;
     // profiling
     bool profiling = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // start, traverse end, vote end, cluster end, boxsum end
     bool ev_valid = false;
 };
 
@@ -326,11 +328,11 @@ static int build_kernel_table(dh_predictor *p) {
 }
 
 static void free_workspace(dh_predictor *p) {
-    void *ptrs[] = {p->leaf_hits, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
+    void *ptrs[] = {p->box, p->leaf_hits, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
                     p->dbg_flags, p->dbg_guess, p->dbg_trace, p->dbg_steps, p->dbg_votes, p->dbg_vcount};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    p->leaf_hits = nullptr;
+    p->box = nullptr; p->leaf_hits = nullptr;
     p->aux_leaf = nullptr; p->aux_flags = nullptr; p->aux_u32 = nullptr; p->aux_out = nullptr; p->aux_out_bytes = 0; p->aux_cap = 0;
     p->ws_frames = nullptr; p->hits = nullptr; p->hit_box = nullptr; p->hit_rot = nullptr; p->counters = nullptr; p->ws_poses = nullptr; p->ws_midp = nullptr;
     p->ws_rot = nullptr; p->ws_mask = nullptr; p->dbg_leaf = nullptr; p->dbg_flags = nullptr; p->dbg_guess = nullptr;
@@ -446,10 +448,14 @@ extern "C" int dh_predictor_sigma(const dh_predictor *p, float *out) {
     return DH_OK;
 }
 
+// Footprint edge of one k_boxsum workgroup (dh_kernels.hip) and the largest rectangle it serves.
+static const int kBoxFoot = 128, kBoxMaxRect = 96;
+
 // Tile of PX x PY window positions per workgroup: as many positions as fit the LDS budget
-// (SAT footprint + leaf ids), at most 1024 (one thread per position in the gate phase).
+// (SAT footprint or box-sum region + leaf ids), at most 1024 (one thread per position in the tail).
 static int choose_tile(const dh_predictor *p, Geom &g) {
     const int step = (int)p->params.stepwidth, sw = (int)p->params.subimage_width, sh = (int)p->params.subimage_height;
+    const int rw = g.uniform ? p->f_rw : 0, rh = g.uniform ? p->f_rh : 0;
     size_t budget = 79 * 1024;   // two 1024-thread workgroups per CU (160 KB LDS)
     if (const char *e = getenv("DH_LDS_BUDGET_KB")) budget = (size_t)atoi(e) * 1024;
     budget = std::min<size_t>(budget, 158 * 1024);
@@ -460,21 +466,30 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
         for (int px = 1; px <= std::min(g.nx, 64); ++px) {
             if (px * py > 1024) continue;
             if (fx > 0 && fy > 0 && (px != std::min(fx, g.nx) || py != std::min(fy, g.ny))) continue;
-            size_t lds = dh_traverse_lds_bytes(px, py, step, sw, sh, (int)p->n_trees);
+            // uniform path: the packed rectangle offsets of a compact node are 14-bit
+            if (rw > 0 && (long)(sh - rh) * dh_traverse_row_stride(px, step, sw, rw) + (sw - rw) >= 16384) continue;
+            size_t lds = dh_traverse_lds_bytes(px, py, step, sw, sh, (int)p->n_trees, rw, rh);
             if (lds > budget && !(fx > 0 && lds <= 158 * 1024)) continue;
             long score = (long)px * py * 1000 - labs((long)px - py);
             if (score > best) { best = score; g.px = px; g.py = py; g.lds = lds; }
         }
     if (best < 0) {
         // a single position must always fit
+        if (rw > 0 && (long)(sh - rh) * dh_traverse_row_stride(1, step, sw, rw) + (sw - rw) >= 16384) return 1;   // caller retries on the general path
         g.px = g.py = 1;
-        g.lds = dh_traverse_lds_bytes(1, 1, step, sw, sh, (int)p->n_trees);
-        if (g.lds > 158 * 1024) return fail(DH_ESIZE, "patch %dx%d with %u trees does not fit LDS", sw, sh, p->n_trees);
+        g.lds = dh_traverse_lds_bytes(1, 1, step, sw, sh, (int)p->n_trees, rw, rh);
+        if (g.lds > 158 * 1024) return rw > 0 ? 1 : fail(DH_ESIZE, "patch %dx%d with %u trees does not fit LDS", sw, sh, p->n_trees);
     }
     g.tiles_x = (g.nx + g.px - 1) / g.px;
     g.tiles_y = (g.ny + g.py - 1) / g.py;
-    g.ss_row = (((g.px - 1) * step + sw) + 1) | 1;
-    g.ss_max = g.ss_row * ((g.py - 1) * step + sh + 1);
+    g.ss_row = dh_traverse_row_stride(g.px, step, sw, rw);
+    g.ss_max = g.ss_row * ((g.py - 1) * step + sh + (rw > 0 ? 1 - rh : 1));
+    if (rw > 0) {
+        g.box_rows = g.h - rh + 1;
+        g.box_pitch = (g.w - rw + 1 + 3) & ~3;
+        g.box_tx = (g.w - rw + 1 + (kBoxFoot - rw)) / (kBoxFoot - rw + 1);
+        g.box_ty = (g.h - rh + 1 + (kBoxFoot - rh)) / (kBoxFoot - rh + 1);
+    }
     return DH_OK;
 }
 
@@ -492,7 +507,14 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     HIP_TRY(hipDeviceSynchronize());
     int cap = std::max(n, same_geom ? p->cap_frames : 0);
     free_workspace(p);
-    if (g.npatch > 0) { rc = choose_tile(p, g); if (rc) return rc; }
+    if (g.npatch > 0) {
+        // uniform-rectangle fast path: one rectangle size (<= 96 x 96, so a k_boxsum workgroup yields
+        // >= 33 x 33 sums), rectangle sums fit i32
+        g.uniform = p->f_uniform && (long)p->f_rw * p->f_rh <= 32768 && p->f_rw <= kBoxMaxRect && p->f_rh <= kBoxMaxRect && !getenv("DH_FORCE_GENERAL");
+        rc = choose_tile(p, g);
+        if (rc > 0) { g.uniform = false; rc = choose_tile(p, g); }   // no tile fits the uniform layout
+        if (rc) return rc;
+    }
     size_t hits_cap = std::max<size_t>((size_t)g.npatch * p->n_trees, 1);
     if (hits_cap > 0xffffffffull) return fail(DH_ESIZE, "too many (patch, tree) pairs per frame");
     p->hits_cap = (uint32_t)hits_cap;
@@ -500,6 +522,7 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     STEP(dev_alloc(p, &p->hits, (size_t)cap * hits_cap));
     STEP(dev_alloc(p, &p->hit_box, (size_t)cap * hits_cap));
     STEP(dev_alloc(p, &p->hit_rot, (size_t)cap * hits_cap));
+    if (g.uniform) STEP(dev_alloc(p, &p->box, (size_t)cap * g.box_rows * g.box_pitch));
     if (p->n_leaves <= DH_LEAF_HIST_MAX && !getenv("DH_NO_LEAF_HIST")) STEP(dev_alloc(p, &p->leaf_hits, (size_t)cap * p->n_leaves));
     STEP(dev_alloc(p, &p->counters, (size_t)cap * (1 + DH_POSGRID + DH_GRID3)));
     STEP(dev_alloc(p, &p->ws_poses, cap));
@@ -516,16 +539,11 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     }
 #undef STEP
     if (rc != DH_OK) { free_workspace(p); return rc; }
-    // uniform-rectangle fast path: box sums fit i32, packed LDS offsets fit 14 bits
-    if (g.npatch > 0) {
-        const long max_off = (long)((int)p->params.subimage_height - p->f_rh) * g.ss_row + ((int)p->params.subimage_width - p->f_rw);
-        g.uniform = p->f_uniform && (long)p->f_rw * p->f_rh <= 32768 && max_off < 16384 && !getenv("DH_FORCE_GENERAL");
-        if (g.uniform && p->nodes_u_ss != g.ss_row) {
-            hipError_t e = dh_launch_nodes_compact(p->dev, g.ss_row, (uint32_t)(p->f_rw * p->f_rh), p->nodes_u, p->own_stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(p->own_stream);
-            if (e != hipSuccess) { free_workspace(p); return fail(DH_EHIP, "k_nodes_compact: %s", hipGetErrorString(e)); }
-            p->nodes_u_ss = g.ss_row;
-        }
+    if (g.npatch > 0 && g.uniform && p->nodes_u_ss != g.ss_row) {     // compact nodes carry LDS offsets for this row stride
+        hipError_t e = dh_launch_nodes_compact(p->dev, g.ss_row, (uint32_t)(p->f_rw * p->f_rh), p->nodes_u, p->own_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->own_stream);
+        if (e != hipSuccess) { free_workspace(p); return fail(DH_EHIP, "k_nodes_compact: %s", hipGetErrorString(e)); }
+        p->nodes_u_ss = g.ss_row;
     }
     p->geom = g;
     p->cap_frames = cap;
@@ -549,6 +567,15 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     const size_t hoff = (size_t)f0 * p->hits_cap;
     const uint16_t *fr = frames + (size_t)f0 * w * h;
     if (profile) HIP_TRY(hipEventRecord(p->ev[0], s));
+    uint32_t *box = g.uniform ? p->box + (size_t)f0 * g.box_rows * g.box_pitch : nullptr;
+    if (g.npatch > 0 && g.uniform) {
+        BoxArgs ba{};
+        ba.frames = fr; ba.n_frames = n; ba.w = w; ba.h = h; ba.rw = p->f_rw; ba.rh = p->f_rh;
+        ba.out = box; ba.pitch = g.box_pitch; ba.rows = g.box_rows;
+        ba.ow = kBoxFoot - p->f_rw + 1; ba.oh = kBoxFoot - p->f_rh + 1; ba.tiles_x = g.box_tx; ba.tiles_y = g.box_ty;
+        HIP_TRY(dh_launch_boxsum(ba, s));
+    }
+    if (profile) HIP_TRY(hipEventRecord(p->ev[4], s));
     if (g.npatch > 0) {
         TraverseArgs ta{};
         ta.frames = fr; ta.n_frames = n; ta.w = w; ta.h = h;
@@ -558,6 +585,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.ss_max = g.ss_max; ta.ss_row = g.ss_row;
         ta.uniform = g.uniform ? 1 : 0; ta.rw = p->f_rw; ta.rh = p->f_rh; ta.area = (uint32_t)(p->f_rw * p->f_rh);
         ta.nodes_u = p->nodes_u;
+        ta.box = box; ta.box_pitch = g.box_pitch; ta.box_rows = g.box_rows;
         if (const char *e = getenv("DH_TRAV_STOP")) ta.stop_phase = atoi(e);
         static unsigned long long *stamps = nullptr;
         if (getenv("DH_TRAV_STAMPS")) {
@@ -892,12 +920,13 @@ extern "C" int dh_get_timing(dh_predictor *p, dh_timing *out) {
     if (!p || !out) return fail(DH_EINVAL, "NULL argument");
     if (!p->ev_valid) return fail(DH_ESTATE, "no profiled batch yet (dh_set_profiling + a batch)");
     HIP_TRY(hipEventSynchronize(p->ev[3]));
-    HIP_TRY(hipEventElapsedTime(&out->traverse_ms, p->ev[0], p->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&out->boxsum_ms, p->ev[0], p->ev[4]));
+    HIP_TRY(hipEventElapsedTime(&out->traverse_ms, p->ev[4], p->ev[1]));
     HIP_TRY(hipEventElapsedTime(&out->vote_ms, p->ev[1], p->ev[2]));
     HIP_TRY(hipEventElapsedTime(&out->cluster_ms, p->ev[2], p->ev[3]));
     HIP_TRY(hipEventElapsedTime(&out->total_ms, p->ev[0], p->ev[3]));
     out->n_frames = (uint32_t)p->last_n;
-    out->reserved = 0;
+
     return DH_OK;
 }
 

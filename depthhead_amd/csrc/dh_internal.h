@@ -85,11 +85,13 @@ struct TraverseArgs {
     int nx, ny;             // patch grid
     int px, py;             // tile size in patches
     int tiles_x, tiles_y;
-    int ss_max;             // LDS SAT capacity in words
-    int ss_row;             // SAT row stride in words (odd), the same for every tile
-    int uniform;            // 1: every split rectangle is rw x rh -> box-sum fast path
+    int ss_max;             // LDS capacity of the SAT (general path) / box-sum region (uniform path) in words
+    int ss_row;             // its row stride in words (general: odd; uniform: a multiple of 4), the same for every tile
+    int uniform;            // 1: every split rectangle is rw x rh -> box-sum fast path fed by k_boxsum
     int rw, rh;
     uint32_t area;          // rw * rh
+    const uint32_t *box;    // uniform path: [n_frames][box_rows][box_pitch] box-sum images written by k_boxsum
+    int box_pitch, box_rows;
     const void *nodes_u;    // NodeU[n_nodes], built by k_nodes_compact for this ss_row
     unsigned long long *dbg_stamps; // profiling: [8] summed cycles per phase over all workgroups (env DH_TRAV_STAMPS)
     int stop_phase;         // profiling knob (env DH_TRAV_STOP): 0 = run everything, k = return after phase k
@@ -103,6 +105,18 @@ struct TraverseArgs {
     uint32_t *leaf_hits;    // nullable [n_frames][n_leaves]: how often each leaf cast rotation votes (zeroed per batch)
     int32_t  *dbg_leaf;     // nullable [n][npatch][T]
     uint8_t  *dbg_flags;    // nullable [n][npatch]
+};
+
+// k_boxsum: per frame the image of all rw x rh rectangle sums, out[y][x] = sum of the rectangle whose
+// top-left pixel is (x, y), for x <= w - rw, y <= h - rh (pitch columns per row, the pad is zeroed).
+struct BoxArgs {
+    const uint16_t *frames;
+    int n_frames, w, h;
+    int rw, rh;
+    uint32_t *out;
+    int pitch, rows;        // row stride in words (multiple of 4), rows = h - rh + 1
+    int ow, oh;             // rectangle origins one workgroup produces: (128 - rw + 1) x (128 - rh + 1)
+    int tiles_x, tiles_y;
 };
 
 struct VoteArgs {
@@ -179,4 +193,7 @@ hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream
 hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s);
 hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s);
 hipError_t dh_launch_votes_dump(const VotesDumpArgs &a, hipStream_t s);
-size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees);
+hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s);
+// rw, rh > 0 selects the uniform (box-sum region) layout, 0 the general (SAT) layout
+size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees, int rw, int rh);
+int dh_traverse_row_stride(int px, int step, int sw, int rw);

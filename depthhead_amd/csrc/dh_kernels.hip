@@ -250,58 +250,150 @@ hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, uint32_t area, vo
 #define TRAV_WAVES (TRAV_THREADS / WAVE)
 #define ROWS_IN_FLIGHT 8
 
-size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees) {
-    size_t fw = (size_t)(px - 1) * step + sw, fh = (size_t)(py - 1) * step + sh;
-    size_t ss = (fw + 1) | 1;      // odd row stride: row-per-lane LDS passes are bank-conflict free
+// Row stride of the LDS image one tile works on.  General path: the (fw + 1)-column SAT with an odd
+// stride (row-per-lane passes are bank-conflict free).  Uniform path (rw > 0): the box-sum region of
+// fw - rw + 1 columns, padded to a multiple of 4 words so that rows are copied with 16-byte accesses.
+int dh_traverse_row_stride(int px, int step, int sw, int rw) {
+    const int fw = (px - 1) * step + sw;
+    return rw > 0 ? (fw - rw + 1 + 3) & ~3 : (fw + 1) | 1;
+}
+size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees, int rw, int rh) {
+    size_t fh = (size_t)(py - 1) * step + sh;
+    size_t ss = (size_t)dh_traverse_row_stride(px, step, sw, rw);
+    size_t rows = rw > 0 ? fh - rh + 1 : fh + 1;
     size_t npt = (size_t)px * py;
-    return (ss * (fh + 1) + npt * n_trees + npt * 3 + npt * 2 + 16) * 4;   // keep in step with the carve-up in k_traverse
+    return (ss * rows + npt * n_trees + npt * 3 + npt * 2 + 16) * 4;   // keep in step with the carve-up in k_traverse
 }
 
-#define STAMP(k)                                                                        \
-    if (a.dbg_stamps && tid == 0) {                                                     \
-        unsigned long long t_ = clock64();                                              \
-        atomicAdd(&a.dbg_stamps[k], t_ - t_prev);                                        \
-        t_prev = t_;                                                                    \
+// Inclusive prefix sum across the 64 lanes of a wave in six DPP adds (no LDS, no barrier):
+// Kogge-Stone inside each 16-lane row, then lane 15 of rows 0/2 into rows 1/3, then lane 31 into
+// the upper half.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// Summed-area table of a footprint of at most 64*PPL columns, built in registers: wave w owns the
+// strip of R = ceil(fh/16) rows starting at w*R.  It loads its rows whole (PPL pixels per lane, fully
+// coalesced), scans each row across the wave with DPP, accumulates down the strip in registers and
+// publishes the strip's bottom row; after one barrier every lane adds the bottom rows of the strips
+// above it and the finished rows are written once.  Three barriers, no serial stitch loop.
+// Returns false when every pixel of the footprint is zero (nothing is written then).
+template <int PPL>
+__device__ __forceinline__ bool sat_rows_dpp(uint32_t *sat, uint32_t *flag, const uint16_t *img, int w, int fx0, int fy0,
+                                             int fw, int fh, int ss) {
+    constexpr int RMAX = 16 / PPL;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int R = (fh + TRAV_WAVES - 1) / TRAV_WAVES;
+    const int y0 = wave * R, x0 = lane * PPL;
+    const bool al = ((w % PPL) == 0) && ((fx0 % PPL) == 0) && ((((size_t)img) & (PPL * 2 - 1)) == 0);
+    uint32_t p[RMAX][PPL];
+    uint32_t any_px = 0;
+    // Every load is issued unconditionally (lanes outside the footprint read its first pixels and are
+    // masked afterwards) so that all RMAX rows are in flight before the first one is consumed.
+    const uint16_t *org = img + (size_t)fy0 * w + fx0;
+    if (al) {
+        const bool fullx = x0 + PPL <= fw;
+        uint32_t raw[RMAX][PPL / 2];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int y = y0 + r;
+            const bool ok = r < R && y < fh && fullx;
+            const uint16_t *row = org + (ok ? (size_t)y * w + x0 : (size_t)0);
+            if (PPL == 2) raw[r][0] = *(const uint32_t *)row;
+            else { const uint2 q = *(const uint2 *)row; raw[r][0] = q.x; raw[r][PPL / 2 - 1] = q.y; }
+        }
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const bool ok = r < R && y0 + r < fh && fullx;
+#pragma unroll
+            for (int c = 0; c < PPL; ++c) {
+                const uint32_t q = raw[r][c >> 1];
+                p[r][c] = ok ? ((c & 1) ? (q >> 16) : (q & 0xffffu)) : 0u;
+            }
+        }
+        if (x0 < fw && !fullx) {                                   // the one ragged lane at the right edge
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r)
+                if (r < R && y0 + r < fh)
+                    for (int c = 0; c < PPL; ++c) if (x0 + c < fw) p[r][c] = org[(size_t)(y0 + r) * w + x0 + c];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+#pragma unroll
+            for (int c = 0; c < PPL; ++c) {
+                const bool ok = r < R && y0 + r < fh && x0 + c < fw;
+                p[r][c] = org[ok ? (size_t)(y0 + r) * w + x0 + c : (size_t)0];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+#pragma unroll
+            for (int c = 0; c < PPL; ++c)
+                if (!(r < R && y0 + r < fh && x0 + c < fw)) p[r][c] = 0;
+        }
     }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+#pragma unroll
+        for (int c = 1; c < PPL; ++c) p[r][c] += p[r][c - 1];
+        const uint32_t tot = p[r][PPL - 1];
+        any_px |= tot;
+        const uint32_t base = wave_incl_scan(tot) - tot;          // sum of the lanes to the left
+#pragma unroll
+        for (int c = 0; c < PPL; ++c) p[r][c] += base;
+        if (r > 0) {
+#pragma unroll
+            for (int c = 0; c < PPL; ++c) p[r][c] += p[r - 1][c];   // rows beyond the strip are zero: the last row carries the total
+        }
+    }
+    if (__ballot(any_px != 0) != 0ull && lane == 0) *flag = 1;
+    uint32_t *Tb = sat;                                            // [16 strips][64 * PPL] bottom rows, inside the unwritten SAT
+#pragma unroll
+    for (int c = 0; c < PPL; ++c) Tb[wave * (WAVE * PPL) + x0 + c] = p[RMAX - 1][c];
+    __syncthreads();
+    if (*flag == 0) return false;
+    uint32_t off[PPL];
+#pragma unroll
+    for (int c = 0; c < PPL; ++c) off[c] = 0;
+    for (int w2 = 0; w2 < wave; ++w2) {
+#pragma unroll
+        for (int c = 0; c < PPL; ++c) off[c] += Tb[w2 * (WAVE * PPL) + x0 + c];
+    }
+    __syncthreads();                                               // the bottom rows are dead: the SAT may overwrite them
+    for (int i = tid; i <= fw; i += TRAV_THREADS) sat[i] = 0;                     // row 0
+    for (int i = tid; i < fh; i += TRAV_THREADS) sat[(i + 1) * ss] = 0;           // column 0
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        const int y = y0 + r;
+        if (r < R && y < fh) {
+            uint32_t *dst = sat + (y + 1) * ss + x0 + 1;
+#pragma unroll
+            for (int c = 0; c < PPL; ++c) if (x0 + c < fw) dst[c] = p[r][c] + off[c];
+        }
+    }
+    __syncthreads();
+    return true;
+}
 
-template <bool UNI>
-__global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+// Pass-based summed-area table (any footprint that fits LDS): vertical running sums from global
+// memory by (4 columns, row segment) units, segment stitching, horizontal prefix sums in LDS.
+__device__ __forceinline__ bool sat_passes(uint32_t *sat, uint32_t *flag, const uint16_t *img, int w, int fx0, int fy0,
+                                           int fw, int fh, int ss) {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int T = (int)a.f.n_trees;
-
-    // XCD-aware block -> (frame, tile): blocks b and b+8 share an XCD (and its L2), so one XCD
-    // walks whole frames and the overlapping tile halos of a frame are re-read from one L2.
-    const int tiles = a.tiles_x * a.tiles_y;
-    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int frame = (j / tiles) * 8 + xcd;
-    const int tile = j % tiles;
-    if (frame >= a.n_frames || a.stop_phase == 9) return;
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int cx = min(a.px, a.nx - tx * a.px), cy = min(a.py, a.ny - ty * a.py);
-    const int npt = cx * cy;
-    const int fx0 = tx * a.px * a.step, fy0 = ty * a.py * a.step;   // footprint origin (pixels)
-    const int fw = (cx - 1) * a.step + a.sw, fh = (cy - 1) * a.step + a.sh;
-    const int ss = a.ss_row;
-
-    uint32_t *sat = lds;
-    int32_t *leaf = (int32_t *)(lds + a.ss_max);
-    float *p3s = (float *)(leaf + a.px * a.py * T);
-    uint32_t *active = (uint32_t *)(p3s + a.px * a.py * 3);
-    uint32_t *pres = active + a.px * a.py;   // per active slot: hit base | gated << 31
-    uint32_t *misc = pres + a.px * a.py;     // [0] n_active, [1] queue head, [2] hit total, [3] hit base, [4] any pixel
-
-    const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
-    unsigned long long t_prev = a.dbg_stamps ? clock64() : 0ull;
-
     // ---- phase 1a: vertical running sums straight from global memory.  Unit = (group of 4
     // columns, segment of rows); a thread issues the loads of up to ROWS_IN_FLIGHT rows (one 8-byte
     // load each when aligned) before it touches them: one global round trip per tile, all lanes
     // busy, no cross-lane traffic.  sat[y+1][x+1] = sum of the column above within the segment.
-    if (tid < 8) misc[tid] = 0;
     for (int i = tid; i <= fw; i += TRAV_THREADS) sat[i] = 0;                     // row 0
     for (int i = tid; i < fh; i += TRAV_THREADS) sat[(i + 1) * ss] = 0;           // column 0
-    const bool al8 = ((a.w & 3) == 0) && ((fx0 & 3) == 0) && ((((size_t)img) & 7) == 0);
+    const bool al8 = ((w & 3) == 0) && ((fx0 & 3) == 0) && ((((size_t)img) & 7) == 0);
     const int CG = (fw + 3) >> 2;
     const int SG = max(1, min(16, TRAV_THREADS / CG));
     const int RV = (fh + SG - 1) / SG;
@@ -317,7 +409,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
                 const int y = y0 + g;
                 p[g][0] = p[g][1] = p[g][2] = p[g][3] = 0;
                 if (y < yb) {
-                    const uint16_t *row = img + (size_t)(fy0 + y) * a.w + fx0 + x;
+                    const uint16_t *row = img + (size_t)(fy0 + y) * w + fx0 + x;
                     if (al8 && x + 3 < fw) {
                         uint2 q = *(const uint2 *)row;
                         p[g][0] = q.x & 0xffffu; p[g][1] = q.x >> 16; p[g][2] = q.y & 0xffffu; p[g][3] = q.y >> 16;
@@ -344,22 +436,9 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         }
         any_px |= r0 | r1 | r2 | r3;
     }
-    if (__ballot(any_px != 0) != 0ull && lane == 0) misc[4] = 1;
+    if (__ballot(any_px != 0) != 0ull && lane == 0) *flag = 1;
     __syncthreads();
-    if (misc[4] == 0) {
-        // every pixel under this tile is zero: all of its windows are background (prediction.rs:567-576)
-        if (a.dbg_flags)
-            for (int p = tid; p < npt; p += TRAV_THREADS) {
-                int gp = (ty * a.py + p / cx) * a.nx + tx * a.px + p % cx;
-                size_t o = (size_t)frame * a.nx * a.ny + gp;
-                a.dbg_flags[o] = 0;
-                if (a.dbg_leaf)
-                    for (int t = 0; t < T; ++t) a.dbg_leaf[o * T + t] = -1;
-            }
-        return;
-    }
-    if (a.stop_phase == 1) return;
-    STAMP(0)
+    if (*flag == 0) return false;
     // ---- phase 1b: stitch the row segments.  First the last row of every segment is made final by
     // one thread per column (a running sum over at most 16 segment totals, loads issued up front),
     // then every other row adds the final value of the segment above it: one read per unit.
@@ -389,7 +468,6 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         }
         __syncthreads();
     }
-    STAMP(1)
     // ---- phase 1c: horizontal prefix sums inside LDS, unit = (row, segment of columns); lanes
     // hold different rows and the row stride is odd, so every access is bank-conflict free.
     // Segment-last columns are stitched like the rows above.
@@ -433,6 +511,168 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             __syncthreads();
         }
     }
+    return true;
+}
+
+// ================================================================== k_boxsum
+// Uniform-rectangle forests (the trainer's geometry, types.rs:82-91): every split test compares the
+// sums of two rw x rh rectangles, so the image of ALL such sums is computed once per frame here
+// and k_traverse only copies the region under its tile.  One workgroup scans a 128 x 128 pixel
+// footprint into an LDS SAT (modulo 2^32; every rectangle sum is < 2^32, so differences are exact)
+// and writes the (128 - rw + 1) x (128 - rh + 1) rectangle sums whose rectangles lie inside it.
+#define BOX_F 128
+#define BOX_SS (BOX_F + 1)
+__global__ void __launch_bounds__(TRAV_THREADS, 8) k_boxsum(BoxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *sat = lds, *flag = lds + BOX_SS * (BOX_F + 1);
+    const int tid = threadIdx.x;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;      // same frame -> XCD mapping as k_traverse
+    const int frame = (j / tiles) * 8 + xcd, tile = j % tiles;
+    if (frame >= a.n_frames) return;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int fx0 = tx * a.ow, fy0 = ty * a.oh;
+    const int fw = min(BOX_F, a.w - fx0), fh = min(BOX_F, a.h - fy0);
+    const int oc = fw - a.rw + 1, orows = fh - a.rh + 1;      // >= 1 by the host's tiling
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    const bool nonzero = sat_rows_dpp<2>(sat, flag, a.frames + (size_t)frame * a.w * a.h, a.w, fx0, fy0, fw, fh, BOX_SS);
+    uint32_t *out = a.out + ((size_t)frame * a.rows + fy0) * a.pitch + fx0;
+    // the last tile of a row also zeroes the pad columns [w - rw + 1, pitch)
+    const int wc = (tx == a.tiles_x - 1) ? a.pitch - fx0 : oc;
+    const int q = TRAV_THREADS / wc, r = TRAV_THREADS - q * wc;
+    int yy = tid / wc, xx = tid - yy * wc;
+    const int jump = a.rh * BOX_SS;
+    while (yy < orows) {
+        uint32_t v = 0;
+        if (nonzero && xx < oc) {
+            const uint32_t *s0 = sat + yy * BOX_SS + xx;
+            v = s0[jump + a.rw] - s0[a.rw] - s0[jump] + s0[0];
+        }
+        out[(size_t)yy * a.pitch + xx] = v;
+        yy += q; xx += r;
+        if (xx >= wc) { xx -= wc; ++yy; }
+    }
+}
+
+hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s) {
+    const int frames8 = (a.n_frames + 7) / 8 * 8;
+    const int grid = frames8 * a.tiles_x * a.tiles_y;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_boxsum, dim3(grid), dim3(TRAV_THREADS), (BOX_SS * (BOX_F + 1) + 4) * sizeof(uint32_t), s, a);
+    return hipGetLastError();
+}
+
+#define STAMP(k)                                                                        \
+    if (a.dbg_stamps && tid == 0) {                                                     \
+        unsigned long long t_ = clock64();                                              \
+        atomicAdd(&a.dbg_stamps[k], t_ - t_prev);                                        \
+        t_prev = t_;                                                                    \
+    }
+
+template <bool UNI>
+__global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int T = (int)a.f.n_trees;
+
+    // XCD-aware block -> (frame, tile): blocks b and b+8 share an XCD (and its L2), so one XCD
+    // walks whole frames and the overlapping tile halos of a frame are re-read from one L2.
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int frame = (j / tiles) * 8 + xcd;
+    const int tile = j % tiles;
+    if (frame >= a.n_frames || a.stop_phase == 9) return;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int cx = min(a.px, a.nx - tx * a.px), cy = min(a.py, a.ny - ty * a.py);
+    const int npt = cx * cy;
+    const int fx0 = tx * a.px * a.step, fy0 = ty * a.py * a.step;   // footprint origin (pixels)
+    const int fw = (cx - 1) * a.step + a.sw, fh = (cy - 1) * a.step + a.sh;
+    const int ss = a.ss_row;
+
+    uint32_t *sat = lds;
+    int32_t *leaf = (int32_t *)(lds + a.ss_max);
+    float *p3s = (float *)(leaf + a.px * a.py * T);
+    uint32_t *active = (uint32_t *)(p3s + a.px * a.py * 3);
+    uint32_t *pres = active + a.px * a.py;   // per active slot: hit base | gated << 31
+    uint32_t *misc = pres + a.px * a.py;     // [0] n_active, [1] queue head, [2] hit total, [3] hit base, [4] any pixel
+
+    const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
+    unsigned long long t_prev = a.dbg_stamps ? clock64() : 0ull;
+
+    // ---- phase 1.  General path: summed-area table of the footprint, modulo 2^32 (footprints of up
+    // to 128 x 128 and 256 x 64 pixels are scanned in registers with DPP wave scans, anything else
+    // takes the pass-based build).  Uniform path: copy the tile's region of the frame's box-sum image
+    // (k_boxsum): slot (y, x) = sum of the rw x rh rectangle whose top-left pixel is (fx0 + x, fy0 + y).
+    if (tid < 8) misc[tid] = 0;
+    __syncthreads();
+    bool nonzero;
+    if (UNI) {
+        const int bw = fw - a.rw + 1, bh = fh - a.rh + 1;
+        const uint32_t *bx = a.box + ((size_t)frame * a.box_rows + fy0) * a.box_pitch + fx0;
+        uint32_t any = 0;
+        const int q4 = (bw + 3) >> 2;                 // 16-byte groups per row; ss >= 4 * q4 by construction
+        if ((fx0 & 3) == 0 && q4 <= WAVE) {
+            // lanes-per-row = next power of two >= q4: a wave copies 64 / lpr rows per pass with one
+            // 16-byte load and one 16-byte LDS store per lane; four passes are in flight per lane.
+            int sh_l = 0;
+            while ((1 << sh_l) < q4) ++sh_l;
+            const int rpw = WAVE >> sh_l, rpp = rpw * TRAV_WAVES;
+            const int lr = lane >> sh_l, lx = lane & ((1 << sh_l) - 1);
+            const bool colok = lx < q4;
+            for (int y0 = (tid >> 6) * rpw + lr; y0 < bh; y0 += 4 * rpp) {
+                uint4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int y = y0 + k * rpp;
+                    const bool ok = colok && y < bh;
+                    v[k] = *(const uint4 *)(bx + (ok ? (size_t)y * a.box_pitch + 4 * lx : (size_t)0));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int y = y0 + k * rpp;
+                    if (colok && y < bh) {
+                        *(uint4 *)(sat + y * ss + 4 * lx) = v[k];
+                        any |= v[k].x | v[k].y | v[k].z | v[k].w;
+                    }
+                }
+            }
+        } else {
+            const int q = TRAV_THREADS / bw, r = TRAV_THREADS - q * bw;
+            int yy = tid / bw, xx = tid - yy * bw;
+            while (yy < bh) {
+                const uint32_t v = bx[(size_t)yy * a.box_pitch + xx];
+                sat[yy * ss + xx] = v;
+                any |= v;
+                yy += q; xx += r;
+                if (xx >= bw) { xx -= bw; ++yy; }
+            }
+        }
+        if (__ballot(any != 0) != 0ull && lane == 0) misc[4] = 1;
+        __syncthreads();
+        nonzero = misc[4] != 0;
+    } else {
+        const int strip = (fh + TRAV_WAVES - 1) / TRAV_WAVES;
+        if (fw <= 2 * WAVE && strip <= 8) nonzero = sat_rows_dpp<2>(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
+        else if (fw <= 4 * WAVE && strip <= 4) nonzero = sat_rows_dpp<4>(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
+        else nonzero = sat_passes(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
+    }
+    if (!nonzero) {
+        // every pixel under this tile is zero (uniform path: every rectangle sum, and the rectangles
+        // cover every window): all of its windows are background (prediction.rs:567-576)
+        if (a.dbg_flags)
+            for (int p = tid; p < npt; p += TRAV_THREADS) {
+                int gp = (ty * a.py + p / cx) * a.nx + tx * a.px + p % cx;
+                size_t o = (size_t)frame * a.nx * a.ny + gp;
+                a.dbg_flags[o] = 0;
+                if (a.dbg_leaf)
+                    for (int t = 0; t < T; ++t) a.dbg_leaf[o * T + t] = -1;
+            }
+        return;
+    }
+    if (a.stop_phase == 1) return;
+    STAMP(0)
+    STAMP(1)
     if (a.stop_phase == 2) return;
     STAMP(2)
 
@@ -440,8 +680,19 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     for (int p = tid; p < npt; p += TRAV_THREADS) {
         int pxi = p % cx, pyi = p / cx;
         int ox = pxi * a.step, oy = pyi * a.step;                      // patch origin inside the footprint
-        uint32_t sum = sat[(oy + a.sh) * ss + ox + a.sw] - sat[oy * ss + ox + a.sw] -
-                       sat[(oy + a.sh) * ss + ox] + sat[oy * ss + ox];
+        uint32_t sum;
+        if (UNI) {
+            // the window is covered by rw x rh rectangles at offsets 0, rw, 2rw, ... (the last one
+            // clamped to sw - rw); pixel values are non-negative, so the window sum is zero exactly
+            // when every one of those rectangle sums is
+            sum = 0;
+            for (int cyk = 0; cyk < a.sh; cyk += a.rh) {
+                const uint32_t *rowp = sat + (oy + min(cyk, a.sh - a.rh)) * ss + ox;
+                for (int cxk = 0; cxk < a.sw; cxk += a.rw) sum |= rowp[min(cxk, a.sw - a.rw)];
+            }
+        } else {
+            sum = sat[(oy + a.sh) * ss + ox + a.sw] - sat[oy * ss + ox + a.sw] - sat[(oy + a.sh) * ss + ox] + sat[oy * ss + ox];
+        }
         int gx = fx0 + ox + a.lw, gy = fy0 + oy + a.lh;                // window centre (x, y)
         float z = (float)img[(size_t)gy * a.w + gx];
         float q[3];
@@ -462,40 +713,6 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     const int n_active = (int)misc[0];
     if (n_active == 0) return;     // nothing to walk, no hits (debug taps were written above)
 
-    // ---- phase 2b (UNI): SAT -> box-sum image, in place.  Slot (y, x) becomes the sum of the
-    // rw x rh rectangle whose top-left is (x, y); it reads slots (y,x) (y,x+rw) (y+rh,x) (y+rh,x+rw),
-    // all at or below/right of the slot it overwrites, so bands of rows are converted top-down:
-    // every thread first computes its cells of the band, then (after a barrier) stores them.
-    if (UNI) {
-        const int bw = fw - a.rw + 1, bh = fh - a.rh + 1;
-        const int BH = max(1, (6 * TRAV_THREADS) / bw);
-        const int q = TRAV_THREADS / bw, r = TRAV_THREADS - q * bw;
-        const int ty0 = tid / bw, tx0 = tid - ty0 * bw;
-        const int jump = a.rh * ss;
-        for (int y0 = 0; y0 < bh; y0 += BH) {
-            const int rows = min(BH, bh - y0);
-            uint32_t v[6];
-            int yy = ty0, xx = tx0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (yy < rows) {
-                    const uint32_t *s0 = sat + (y0 + yy) * ss + xx;
-                    v[k] = s0[jump + a.rw] - s0[a.rw] - s0[jump] + s0[0];
-                }
-                yy += q; xx += r;
-                if (xx >= bw) { xx -= bw; ++yy; }
-            }
-            __syncthreads();
-            yy = ty0; xx = tx0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (yy < rows) sat[(y0 + yy) * ss + xx] = v[k];
-                yy += q; xx += r;
-                if (xx >= bw) { xx -= bw; ++yy; }
-            }
-            __syncthreads();
-        }
-    }
     STAMP(4)
     // ---- phase 3: root->leaf walks.  Work item k = (tree k / n_active, active slot k % n_active),
     // lane = k mod 1024: the lanes of a wave walk the SAME tree for NEIGHBOURING windows (4 px apart),
@@ -702,6 +919,7 @@ hipError_t dh_kernels_init() {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_boxsum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }

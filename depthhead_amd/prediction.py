@@ -208,8 +208,8 @@ class HoughPrediction:
     def timing(self) -> dict:
         t = _lib.Timing()
         check(self._lib.dh_get_timing(self._ph, C.byref(t)))
-        return {"traverse_ms": t.traverse_ms, "vote_ms": t.vote_ms, "cluster_ms": t.cluster_ms,
-                "total_ms": t.total_ms, "n_frames": t.n_frames}
+        return {"boxsum_ms": t.boxsum_ms, "traverse_ms": t.traverse_ms, "vote_ms": t.vote_ms,
+                "cluster_ms": t.cluster_ms, "total_ms": t.total_ms, "n_frames": t.n_frames}
 
     # ---- parity taps (tests) -------------------------------------------------------------
     def debug_enable(self, on: bool = True) -> None:
