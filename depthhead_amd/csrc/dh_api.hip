@@ -182,7 +182,7 @@ struct Geom {
     int w = 0, h = 0, nx = 0, ny = 0, npatch = 0;
     int px = 0, py = 0, tiles_x = 0, tiles_y = 0, ss_max = 0, ss_row = 0;
     bool uniform = false;       // uniform-rectangle path: k_boxsum feeds k_traverse<true>
-    int box_pitch = 0, box_rows = 0, box_tx = 0, box_ty = 0;
+    int box_pitch = 0, box_rows = 0, box_ow = 0, box_oh = 0, box_parts = 0, box_bands = 0;
     size_t lds = 0;
 };
 
@@ -229,6 +229,7 @@ struct dh_predictor {
     DevForest dev{};
     std::vector<void *> forest_allocs;
     float *kern_ord = nullptr;   // device, 8000 floats
+    uint16_t *zeros = nullptr;   // device, 64 zero bytes (k_boxsum reads them for columns right of the image)
     bool f_uniform = false;      // forest has one split-rectangle size
     int f_rw = 0, f_rh = 0;
     void *nodes_u = nullptr;     // 16-byte compact nodes for the current ss_row (uniform path)
@@ -350,6 +351,7 @@ extern "C" int dh_predictor_destroy(dh_predictor *p) {
     free_workspace(p);
     for (void *q : p->forest_allocs) (void)hipFree(q);
     if (p->kern_ord) (void)hipFree(p->kern_ord);
+    if (p->zeros) (void)hipFree(p->zeros);
     for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     for (auto &e : p->ev_join) if (e) (void)hipEventDestroy(e);
@@ -404,11 +406,13 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     STEP(dev_alloc(p, &d.rbin_box_hi, p->n_leaves, true));
     STEP(dev_alloc(p, &d.tpl, p->n_leaves, true));
     STEP(dev_alloc(p, &p->kern_ord, DH_GRID3));
+    STEP(dev_alloc(p, &p->zeros, 32));
     { uint4 *nu = nullptr; STEP(dev_alloc(p, &nu, p->n_nodes, true)); p->nodes_u = nu; }
 #undef STEP
     auto hipstep = [&](hipError_t e, const char *what) {
         if (rc == DH_OK && e != hipSuccess) rc = fail(DH_EHIP, "%s: %s", what, hipGetErrorString(e));
     };
+    if (rc == DH_OK) hipstep(hipMemset(p->zeros, 0, 64), "hipMemset");
     if (rc == DH_OK) hipstep(dh_kernels_init(), "hipFuncSetAttribute");
     if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking), "hipStreamCreate");
     if (rc == DH_OK) hipstep(dh_launch_leaf_prepare(d, p->own_stream), "k_leaf_prepare launch");
@@ -448,8 +452,8 @@ extern "C" int dh_predictor_sigma(const dh_predictor *p, float *out) {
     return DH_OK;
 }
 
-// Footprint edge of one k_boxsum workgroup (dh_kernels.hip) and the largest rectangle it serves.
-static const int kBoxFoot = 128, kBoxMaxRect = 96;
+// Image columns one k_boxsum wave spans (dh_kernels.hip) and the largest rectangle edge it serves.
+static const int kBoxSpan = 256, kBoxMaxRect = 96;
 
 // Tile of PX x PY window positions per workgroup: as many positions as fit the LDS budget
 // (SAT footprint or box-sum region + leaf ids), at most 1024 (one thread per position in the tail).
@@ -487,8 +491,15 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
     if (rw > 0) {
         g.box_rows = g.h - rh + 1;
         g.box_pitch = (g.w - rw + 1 + 3) & ~3;
-        g.box_tx = (g.w - rw + 1 + (kBoxFoot - rw)) / (kBoxFoot - rw + 1);
-        g.box_ty = (g.h - rh + 1 + (kBoxFoot - rh)) / (kBoxFoot - rh + 1);
+        // one wave yields up to 256 - rw columns (a multiple of 4) of a band of rows; bands are sized so
+        // that a batch of a few hundred frames fills the chip once (about 24 waves per frame at VGA)
+        const int bw = g.w - rw + 1, ow_max = (kBoxSpan - rw) & ~3;
+        g.box_parts = (bw + ow_max - 1) / ow_max;
+        g.box_ow = std::min(ow_max, ((bw + g.box_parts - 1) / g.box_parts + 3) & ~3);
+        int band = 64;
+        if (const char *e = getenv("DH_BOX_BAND")) band = std::max(1, atoi(e));
+        g.box_bands = (g.box_rows + band - 1) / band;
+        g.box_oh = (g.box_rows + g.box_bands - 1) / g.box_bands;
     }
     return DH_OK;
 }
@@ -508,8 +519,8 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     int cap = std::max(n, same_geom ? p->cap_frames : 0);
     free_workspace(p);
     if (g.npatch > 0) {
-        // uniform-rectangle fast path: one rectangle size (<= 96 x 96, so a k_boxsum workgroup yields
-        // >= 33 x 33 sums), rectangle sums fit i32
+        // uniform-rectangle fast path: one rectangle size (<= 96 x 96, so a k_boxsum wave yields
+        // >= 160 columns), rectangle sums fit i32
         g.uniform = p->f_uniform && (long)p->f_rw * p->f_rh <= 32768 && p->f_rw <= kBoxMaxRect && p->f_rh <= kBoxMaxRect && !getenv("DH_FORCE_GENERAL");
         rc = choose_tile(p, g);
         if (rc > 0) { g.uniform = false; rc = choose_tile(p, g); }   // no tile fits the uniform layout
@@ -570,9 +581,10 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     uint32_t *box = g.uniform ? p->box + (size_t)f0 * g.box_rows * g.box_pitch : nullptr;
     if (g.npatch > 0 && g.uniform) {
         BoxArgs ba{};
-        ba.frames = fr; ba.n_frames = n; ba.w = w; ba.h = h; ba.rw = p->f_rw; ba.rh = p->f_rh;
+        ba.frames = fr; ba.zeros = p->zeros; ba.n_frames = n; ba.w = w; ba.h = h; ba.rw = p->f_rw; ba.rh = p->f_rh;
         ba.out = box; ba.pitch = g.box_pitch; ba.rows = g.box_rows;
-        ba.ow = kBoxFoot - p->f_rw + 1; ba.oh = kBoxFoot - p->f_rh + 1; ba.tiles_x = g.box_tx; ba.tiles_y = g.box_ty;
+        ba.ow = g.box_ow; ba.oh = g.box_oh; ba.parts = g.box_parts; ba.bands = g.box_bands;
+        ba.blocks_per_frame = (g.box_parts * g.box_bands + 3) / 4;
         HIP_TRY(dh_launch_boxsum(ba, s));
     }
     if (profile) HIP_TRY(hipEventRecord(p->ev[4], s));

@@ -111,12 +111,14 @@ struct TraverseArgs {
 // top-left pixel is (x, y), for x <= w - rw, y <= h - rh (pitch columns per row, the pad is zeroed).
 struct BoxArgs {
     const uint16_t *frames;
+    const uint16_t *zeros;  // >= 8 zero bytes, 8-byte aligned (stands in for the columns right of the image)
     int n_frames, w, h;
     int rw, rh;
     uint32_t *out;
     int pitch, rows;        // row stride in words (multiple of 4), rows = h - rh + 1
-    int ow, oh;             // rectangle origins one workgroup produces: (128 - rw + 1) x (128 - rh + 1)
-    int tiles_x, tiles_y;
+    int ow, oh;             // rectangle origins one wave produces: ow columns (multiple of 4, <= 256 - rw) x oh rows
+    int parts, bands;       // waves across / down a frame
+    int blocks_per_frame;   // ceil(parts * bands / 4)
 };
 
 struct VoteArgs {

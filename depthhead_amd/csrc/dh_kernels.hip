@@ -517,50 +517,165 @@ __device__ __forceinline__ bool sat_passes(uint32_t *sat, uint32_t *flag, const 
 // ================================================================== k_boxsum
 // Uniform-rectangle forests (the trainer's geometry, types.rs:82-91): every split test compares the
 // sums of two rw x rh rectangles, so the image of ALL such sums is computed once per frame here
-// and k_traverse only copies the region under its tile.  One workgroup scans a 128 x 128 pixel
-// footprint into an LDS SAT (modulo 2^32; every rectangle sum is < 2^32, so differences are exact)
-// and writes the (128 - rw + 1) x (128 - rh + 1) rectangle sums whose rectangles lie inside it.
-#define BOX_F 128
-#define BOX_SS (BOX_F + 1)
-__global__ void __launch_bounds__(TRAV_THREADS, 8) k_boxsum(BoxArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *sat = lds, *flag = lds + BOX_SS * (BOX_F + 1);
-    const int tid = threadIdx.x;
-    const int tiles = a.tiles_x * a.tiles_y;
-    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;      // same frame -> XCD mapping as k_traverse
-    const int frame = (j / tiles) * 8 + xcd, tile = j % tiles;
-    if (frame >= a.n_frames) return;
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int fx0 = tx * a.ow, fy0 = ty * a.oh;
-    const int fw = min(BOX_F, a.w - fx0), fh = min(BOX_F, a.h - fy0);
-    const int oc = fw - a.rw + 1, orows = fh - a.rh + 1;      // >= 1 by the host's tiling
-    if (tid == 0) *flag = 0;
-    __syncthreads();
-    const bool nonzero = sat_rows_dpp<2>(sat, flag, a.frames + (size_t)frame * a.w * a.h, a.w, fx0, fy0, fw, fh, BOX_SS);
-    uint32_t *out = a.out + ((size_t)frame * a.rows + fy0) * a.pitch + fx0;
-    // the last tile of a row also zeroes the pad columns [w - rw + 1, pitch)
-    const int wc = (tx == a.tiles_x - 1) ? a.pitch - fx0 : oc;
-    const int q = TRAV_THREADS / wc, r = TRAV_THREADS - q * wc;
-    int yy = tid / wc, xx = tid - yy * wc;
-    const int jump = a.rh * BOX_SS;
-    while (yy < orows) {
-        uint32_t v = 0;
-        if (nonzero && xx < oc) {
-            const uint32_t *s0 = sat + yy * BOX_SS + xx;
-            v = s0[jump + a.rw] - s0[a.rw] - s0[jump] + s0[0];
-        }
-        out[(size_t)yy * a.pitch + xx] = v;
-        yy += q; xx += r;
-        if (xx >= wc) { xx -= wc; ++yy; }
+// and k_traverse only copies the region under its tile.  out[y][x] = sum of the pixels of the
+// rectangle whose top-left pixel is (x, y) -- an exact integer < 2^32, so any order of summation
+// gives the reference's value (types.rs:317-339 adds the same pixels one by one).
+//
+// Streaming, barrier-free: one WAVE owns a band of `oh` output rows x 256 image columns (4 per
+// lane) and marches down it.  Per row it adds the entering image row to / subtracts the leaving
+// row from its per-column running sums V (the rh-row vertical sums), prefix-sums V across the wave
+// (3 adds + the 6-DPP scan), parks the exclusive prefix in a wave-private LDS row and reads it back
+// rw columns to the right: out[x] = Pex[x + rw] - Pex[x].  One 8-byte load per image row and lane,
+// one 16-byte store per output row and lane.
+#define BOXW_THREADS 256
+#define BOXW_WAVES (BOXW_THREADS / WAVE)
+#define BOX_SPAN 256             // image columns per wave
+#define BOX_MAXR 96              // largest rectangle edge (host: kBoxMaxRect)
+#define BOX_ROWS_IN_FLIGHT 4
+
+// AL: 8-byte row loads (w % 4 == 0, 8-byte aligned frames: a lane is all inside or all outside the
+// image); RW4: rw % 4 == 0 (the shifted prefix is read back with one 16-byte LDS load).  Both are
+// uniform, and compile-time here so that the loads of a group stay straight-line code.
+template <bool AL, bool RW4, int RIF>
+__device__ __forceinline__ void boxsum_wave(const BoxArgs &a, const uint16_t *img, uint32_t *pex, uint32_t *out,
+                                            int lane, int x, int Y0, int y_end, bool store) {
+    // Columns right of the image read a.zeros with row stride 0 instead of being masked, so every
+    // load is unconditional and nothing has to wait for it before its use.
+    const bool in0 = x < a.w, in1 = x + 1 < a.w, in2 = x + 2 < a.w, in3 = x + 3 < a.w;
+    const uint16_t *c0 = in0 ? img + x : a.zeros, *c1 = in1 ? img + x + 1 : a.zeros;
+    const uint16_t *c2 = in2 ? img + x + 2 : a.zeros, *c3 = in3 ? img + x + 3 : a.zeros;
+    const size_t s0 = in0 ? a.w : 0, s1 = in1 ? a.w : 0, s2 = in2 ? a.w : 0, s3 = in3 ? a.w : 0;
+    auto load_row = [&](int y) -> uint2 {
+        if (AL) return *(const uint2 *)(c0 + (size_t)y * s0);
+        return make_uint2((uint32_t)c0[(size_t)y * s0] | ((uint32_t)c1[(size_t)y * s1] << 16),
+                          (uint32_t)c2[(size_t)y * s2] | ((uint32_t)c3[(size_t)y * s3] << 16));
+    };
+    // Step t brings image row Y0 + t into the rh-row window; from t = rh - 1 on it also emits output
+    // row Y0 + t - (rh - 1) and then drops that row from the window.  Steps run in groups of
+    // RIF (rows in flight; 1 on the 2-byte-load path to stay within 64 VGPRs) whose loads are issued one whole group ahead of their use (during the
+    // warm-up steps the "leaving" loads fetch row Y0 and are ignored).
+    const int nsteps = (a.rh - 1) + (y_end - Y0), warm = a.rh - 1;
+    const uint32_t *pex_rd = pex + 4 * lane + a.rw;
+    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    uint2 e[RIF], l[RIF], en[RIF], ln[RIF];
+#pragma unroll
+    for (int k = 0; k < RIF; ++k) {
+        const int t = min(k, nsteps - 1);
+        e[k] = load_row(Y0 + t);
+        l[k] = load_row(Y0 + max(t - warm, 0));
     }
+    for (int t0 = 0; t0 < nsteps; t0 += RIF) {
+#pragma unroll
+        for (int k = 0; k < RIF; ++k) {
+            const int t = min(t0 + RIF + k, nsteps - 1);
+            en[k] = load_row(Y0 + t);
+            ln[k] = load_row(Y0 + max(t - warm, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < RIF; ++k) {
+            const int t = t0 + k;
+            if (t >= nsteps) break;
+            v0 += e[k].x & 0xffffu; v1 += e[k].x >> 16; v2 += e[k].y & 0xffffu; v3 += e[k].y >> 16;
+            if (t < warm) continue;
+            const uint32_t e1 = v0, e2 = v0 + v1, e3 = e2 + v2, tot = e3 + v3;
+            const uint32_t base = wave_incl_scan(tot) - tot;               // sum of the columns left of this lane
+            const uint4 pe = make_uint4(base, base + e1, base + e2, base + e3);
+            __builtin_amdgcn_wave_barrier();                               // the previous row's reads are issued
+            *(uint4 *)(pex + 4 * lane) = pe;
+            __builtin_amdgcn_wave_barrier();                               // LDS is in order within a wave
+            uint4 r;
+            if (RW4) r = *(const uint4 *)__builtin_assume_aligned(pex_rd, 16);
+            else r = make_uint4(pex_rd[0], pex_rd[1], pex_rd[2], pex_rd[3]);
+            if (store) *(uint4 *)(out + (size_t)(Y0 + t - warm) * a.pitch) = make_uint4(r.x - pe.x, r.y - pe.y, r.z - pe.z, r.w - pe.w);
+            v0 -= l[k].x & 0xffffu; v1 -= l[k].x >> 16; v2 -= l[k].y & 0xffffu; v3 -= l[k].y >> 16;
+        }
+#pragma unroll
+        for (int k = 0; k < RIF; ++k) { e[k] = en[k]; l[k] = ln[k]; }
+    }
+}
+
+__global__ void __launch_bounds__(BOXW_THREADS) k_boxsum(BoxArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t pex_s[BOXW_WAVES][BOX_SPAN + BOX_MAXR + 8];
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;      // same frame -> XCD mapping as k_traverse
+    const int frame = (j / a.blocks_per_frame) * 8 + xcd;
+    const int unit = (j % a.blocks_per_frame) * BOXW_WAVES + wv;
+    if (frame >= a.n_frames || unit >= a.bands * a.parts) return;      // waves are independent: no barriers below
+    const int band = unit / a.parts, part = unit - band * a.parts;
+    const int X0 = part * a.ow, Y0 = band * a.oh;           // X0 % 4 == 0 (host)
+    const int y_end = min(Y0 + a.oh, a.rows);
+    if (Y0 >= a.rows) return;
+    const int x = X0 + 4 * lane;                            // this lane's columns x .. x + 3
+    const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
+    const bool store = 4 * lane < a.ow && x < a.pitch;      // pad columns [w - rw + 1, pitch) get clipped-rectangle sums
+    uint32_t *pex = pex_s[wv];
+    uint32_t *out = a.out + (size_t)frame * a.rows * a.pitch + x;
+    const bool al = (a.w & 3) == 0 && (((size_t)a.frames) & 7) == 0, rw4 = (a.rw & 3) == 0;
+    if (al && rw4) boxsum_wave<true, true, BOX_ROWS_IN_FLIGHT>(a, img, pex, out, lane, x, Y0, y_end, store);
+    else if (al) boxsum_wave<true, false, BOX_ROWS_IN_FLIGHT>(a, img, pex, out, lane, x, Y0, y_end, store);
+    else if (rw4) boxsum_wave<false, true, 1>(a, img, pex, out, lane, x, Y0, y_end, store);
+    else boxsum_wave<false, false, 1>(a, img, pex, out, lane, x, Y0, y_end, store);
 }
 
 hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s) {
     const int frames8 = (a.n_frames + 7) / 8 * 8;
-    const int grid = frames8 * a.tiles_x * a.tiles_y;
+    const int grid = frames8 * a.blocks_per_frame;
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_boxsum, dim3(grid), dim3(TRAV_THREADS), (BOX_SS * (BOX_F + 1) + 4) * sizeof(uint32_t), s, a);
+    hipLaunchKernelGGL(k_boxsum, dim3(grid), dim3(BOXW_THREADS), 0, s, a);
     return hipGetLastError();
+}
+
+// Root-to-leaf walks of the uniform path: work item k = (tree k / n_active, active slot k % n_active);
+// a lane takes items tid, tid + 1024, ... W at a time.  HoughTreeFunctions::binarize
+// (houghforest.rs:185-193) on two rectangle sums with the integer test of NodeU, falling back to
+// the reference's own f64 arithmetic inside the band the integer test cannot decide.
+template <int W>
+__device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32_t *sat, int32_t *leaf, const uint32_t *active,
+                                             int n_active, int total, int cx, int ss, int T) {
+    const int tid = threadIdx.x;
+    const NodeU *nodes_u = (const NodeU *)a.nodes_u;
+    for (int k0 = tid; k0 < total; k0 += W * TRAV_THREADS) {
+        int cur[W], dst[W];
+        const uint32_t *sp[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const int k = k0 + i * TRAV_THREADS;
+            const bool has = k < total;
+            const int kk = has ? k : k0;
+            const int t = kk / n_active, slot = kk - t * n_active;
+            const int p = (int)active[slot];
+            const int py = p / cx, px = p - py * cx;
+            sp[i] = sat + py * a.step * ss + px * a.step;
+            dst[i] = p * T + t;
+            cur[i] = has ? a.f.roots[t] : -1;
+        }
+        for (;;) {
+            bool go = false;
+#pragma unroll
+            for (int i = 0; i < W; ++i) go |= cur[i] >= 0;
+            if (!go) break;
+            uint4 n[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) n[i] = *(const uint4 *)(nodes_u + (cur[i] >= 0 ? cur[i] : 0));   // a finished walk re-reads node 0 harmlessly
+            uint32_t s1[W], s2[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) { s1[i] = sp[i][n[i].x & 0x3fffu]; s2[i] = sp[i][(n[i].x >> 14) & 0x3fffu]; }
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const int32_t d = (int32_t)s1[i] - (int32_t)s2[i];
+                bool one = d > (int32_t)n[i].y;
+                const uint32_t amb = n[i].x >> 28;
+                if (cur[i] >= 0 && amb && one && d <= (int32_t)n[i].y + (int32_t)amb) {
+                    const double thr = a.f.nodes[cur[i]].threshold, c = (double)a.area;
+                    one = __dsub_rn(__ddiv_rn((double)s1[i], c), __ddiv_rn((double)s2[i], c)) > thr;   // types.rs:338
+                }
+                if (cur[i] >= 0) cur[i] = one ? (int)n[i].w : (int)n[i].z;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            if (k0 + i * TRAV_THREADS < total) leaf[dst[i]] = ~cur[i];
+    }
 }
 
 #define STAMP(k)                                                                        \
@@ -599,6 +714,10 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
 
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
     unsigned long long t_prev = a.dbg_stamps ? clock64() : 0ull;
+    // depth at the centre of this thread's window (phase 2), requested now so that its latency
+    // hides behind phase 1
+    uint16_t zc = 0;
+    if (tid < npt) zc = img[(size_t)(fy0 + (tid / cx) * a.step + a.lh) * a.w + fx0 + (tid % cx) * a.step + a.lw];
 
     // ---- phase 1.  General path: summed-area table of the footprint, modulo 2^32 (footprints of up
     // to 128 x 128 and 256 x 64 pixels are scanned in registers with DPP wave scans, anything else
@@ -677,7 +796,8 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     STAMP(2)
 
     // ---- phase 2: per patch: centre -> 3-D (prediction.rs:551-554), background gate (:567-571)
-    for (int p = tid; p < npt; p += TRAV_THREADS) {
+    if (tid < npt) {                                                   // npt <= 1024: one window per thread
+        const int p = tid;
         int pxi = p % cx, pyi = p / cx;
         int ox = pxi * a.step, oy = pyi * a.step;                      // patch origin inside the footprint
         uint32_t sum;
@@ -694,7 +814,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             sum = sat[(oy + a.sh) * ss + ox + a.sw] - sat[oy * ss + ox + a.sw] - sat[(oy + a.sh) * ss + ox] + sat[oy * ss + ox];
         }
         int gx = fx0 + ox + a.lw, gy = fy0 + oy + a.lh;                // window centre (x, y)
-        float z = (float)img[(size_t)gy * a.w + gx];
+        float z = (float)zc;
         float q[3];
         to3d(a.kinv, (float)gx, (float)gy, z, q);
         p3s[p * 3 + 0] = q[0]; p3s[p * 3 + 1] = q[1]; p3s[p * 3 + 2] = q[2];
@@ -724,43 +844,14 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // Trees are validated acyclic on the host, so every walk ends.
     const int total = n_active * T;
     if (UNI) {
-        // Two walks per lane, advanced in lock step: their node fetches and box-sum reads are
-        // independent, so each lane keeps two dependent-load chains in flight.
-        const NodeU *nodes_u = (const NodeU *)a.nodes_u;
-        for (int k = tid; k < total; k += 2 * TRAV_THREADS) {
-            const int kb = k + TRAV_THREADS;
-            const bool hasb = kb < total;
-            const int ta = k / n_active, sa = k - ta * n_active;
-            const int tb = hasb ? kb / n_active : ta, sb = hasb ? kb - tb * n_active : sa;
-            const int pa = (int)active[sa], pb = (int)active[sb];
-            const int pya = pa / cx, pxa = pa - pya * cx, pyb = pb / cx, pxb = pb - pyb * cx;
-            const uint32_t *spa = sat + pya * a.step * ss + pxa * a.step;
-            const uint32_t *spb = sat + pyb * a.step * ss + pxb * a.step;
-            int ca = a.f.roots[ta], cb = hasb ? a.f.roots[tb] : -1;
-            while (ca >= 0 || cb >= 0) {
-                const int ia = ca >= 0 ? ca : 0, ib = cb >= 0 ? cb : 0;      // a finished walk re-reads node 0 harmlessly
-                const uint4 na = *(const uint4 *)(nodes_u + ia), nb = *(const uint4 *)(nodes_u + ib);
-                const uint32_t a1 = spa[na.x & 0x3fffu], a2 = spa[(na.x >> 14) & 0x3fffu];
-                const uint32_t b1 = spb[nb.x & 0x3fffu], b2 = spb[(nb.x >> 14) & 0x3fffu];
-                // HoughTreeFunctions::binarize (houghforest.rs:185-193): two box sums, integer test
-                const int32_t da = (int32_t)a1 - (int32_t)a2, db = (int32_t)b1 - (int32_t)b2;
-                bool onea = da > (int32_t)na.y, oneb = db > (int32_t)nb.y;
-                const uint32_t amba = na.x >> 28, ambb = nb.x >> 28;
-                if (ca >= 0 && amba && onea && da <= (int32_t)na.y + (int32_t)amba) {
-                    // inside the band the integer test cannot decide: the reference's own arithmetic
-                    const double thr = a.f.nodes[ca].threshold, c = (double)a.area;
-                    onea = __dsub_rn(__ddiv_rn((double)a1, c), __ddiv_rn((double)a2, c)) > thr;   // types.rs:338
-                }
-                if (cb >= 0 && ambb && oneb && db <= (int32_t)nb.y + (int32_t)ambb) {
-                    const double thr = a.f.nodes[cb].threshold, c = (double)a.area;
-                    oneb = __dsub_rn(__ddiv_rn((double)b1, c), __ddiv_rn((double)b2, c)) > thr;
-                }
-                if (ca >= 0) ca = onea ? (int)na.w : (int)na.z;
-                if (cb >= 0) cb = oneb ? (int)nb.w : (int)nb.z;
-            }
-            leaf[pa * T + ta] = ~ca;
-            if (hasb) leaf[pb * T + tb] = ~cb;
-        }
+        // W walks per lane, advanced in lock step: their node fetches and box-sum reads are
+        // independent, so each lane keeps W dependent-load chains in flight.  W = walks per lane
+        // of this tile (at most 4), so one pass covers the tile whenever it has <= 4096 walks.
+        const int per_lane = (total + TRAV_THREADS - 1) / TRAV_THREADS;
+        if (per_lane <= 1) walk_uniform<1>(a, sat, leaf, active, n_active, total, cx, ss, T);
+        else if (per_lane == 2) walk_uniform<2>(a, sat, leaf, active, n_active, total, cx, ss, T);
+        else if (per_lane == 3) walk_uniform<3>(a, sat, leaf, active, n_active, total, cx, ss, T);
+        else walk_uniform<4>(a, sat, leaf, active, n_active, total, cx, ss, T);
     } else {
         for (int k = tid; k < total; k += TRAV_THREADS) {
             const int t = k / n_active, slot = k - t * n_active;
@@ -919,7 +1010,6 @@ hipError_t dh_kernels_init() {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_boxsum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
