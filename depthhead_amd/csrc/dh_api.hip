@@ -180,9 +180,10 @@ extern "C" int dh_forest_info(const dh_forest *f, uint32_t *n_trees, uint32_t *n
 // ------------------------------------------------------------------ geometry
 struct Geom {
     int w = 0, h = 0, nx = 0, ny = 0, npatch = 0;
-    int px = 0, py = 0, tiles_x = 0, tiles_y = 0, ss_max = 0, ss_row = 0;
+    int px = 0, py = 0, tiles_x = 0, tiles_y = 0, ss_max = 0, ss_row = 0, swz_log2 = 0, swz_q = 0;
     bool uniform = false;       // uniform-rectangle path: k_boxsum feeds k_traverse<true>
-    int box_pitch = 0, box_rows = 0, box_ow = 0, box_oh = 0, box_parts = 0, box_bands = 0;
+    int flag_words = 0;                // per frame: u32 words holding one flag byte per tile (uniform path)
+    int box_plane = 0, box_rows = 0, box_ow = 0, box_oh = 0, box_parts = 0, box_bands = 0;
     size_t lds = 0;
 };
 
@@ -232,8 +233,8 @@ struct dh_predictor {
     uint16_t *zeros = nullptr;   // device, 64 zero bytes (k_boxsum reads them for columns right of the image)
     bool f_uniform = false;      // forest has one split-rectangle size
     int f_rw = 0, f_rh = 0;
-    void *nodes_u = nullptr;     // 16-byte compact nodes for the current ss_row (uniform path)
-    int nodes_u_ss = 0;
+    void *nodes_u = nullptr;     // 16-byte compact nodes for the current region layout (uniform path)
+    long long nodes_u_key = 0;   // (ss_row, swizzle) the compact nodes were built for
     hipStream_t own_stream = nullptr;
     int chunks = 1;                       // sub-batches per call (env DH_CHUNKS)
     hipStream_t aux_stream[DH_MAX_CHUNKS - 1] = {};
@@ -246,7 +247,7 @@ struct dh_predictor {
     HitRec *hits = nullptr;
     HitBox *hit_box = nullptr;
     HitRot *hit_rot = nullptr;
-    uint32_t *box = nullptr;         // [cap][box_rows][box_pitch] rectangle-sum images (uniform path)
+    uint32_t *box = nullptr;         // [cap][box_rows][m][box_plane] rectangle-sum images (uniform path)
     uint32_t *leaf_hits = nullptr;   // [cap][n_leaves] rotation-vote histogram, only for forests of <= DH_LEAF_HIST_MAX leaves
     uint32_t hits_cap = 0;
     uint32_t *counters = nullptr;    // [n] hit_count | [n][400] pos_grid | [n][8000] rot_grid (one memset)
@@ -470,8 +471,10 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
         for (int px = 1; px <= std::min(g.nx, 64); ++px) {
             if (px * py > 1024) continue;
             if (fx > 0 && fy > 0 && (px != std::min(fx, g.nx) || py != std::min(fy, g.ny))) continue;
+            // uniform path: tiles start on 16-byte boundaries of the box image's planes (direct-to-LDS copy)
+            if (rw > 0 && (px & 3) != 0 && px < g.nx && !(fx > 0)) continue;
             // uniform path: the packed rectangle offsets of a compact node are 14-bit
-            if (rw > 0 && (long)(sh - rh) * dh_traverse_row_stride(px, step, sw, rw) + (sw - rw) >= 16384) continue;
+            if (rw > 0 && (long)(sh - rh + 1) * dh_traverse_row_stride(px, step, sw, rw) >= 16384) continue;
             size_t lds = dh_traverse_lds_bytes(px, py, step, sw, sh, (int)p->n_trees, rw, rh);
             if (lds > budget && !(fx > 0 && lds <= 158 * 1024)) continue;
             long score = (long)px * py * 1000 - labs((long)px - py);
@@ -479,7 +482,7 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
         }
     if (best < 0) {
         // a single position must always fit
-        if (rw > 0 && (long)(sh - rh) * dh_traverse_row_stride(1, step, sw, rw) + (sw - rw) >= 16384) return 1;   // caller retries on the general path
+        if (rw > 0 && (long)(sh - rh + 1) * dh_traverse_row_stride(1, step, sw, rw) >= 16384) return 1;   // caller retries on the general path
         g.px = g.py = 1;
         g.lds = dh_traverse_lds_bytes(1, 1, step, sw, sh, (int)p->n_trees, rw, rh);
         if (g.lds > 158 * 1024) return rw > 0 ? 1 : fail(DH_ESIZE, "patch %dx%d with %u trees does not fit LDS", sw, sh, p->n_trees);
@@ -487,10 +490,15 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
     g.tiles_x = (g.nx + g.px - 1) / g.px;
     g.tiles_y = (g.ny + g.py - 1) / g.py;
     g.ss_row = dh_traverse_row_stride(g.px, step, sw, rw);
+    if (rw > 0) dh_traverse_swizzle(g.px, step, sw, rw, &g.swz_log2, &g.swz_q, &g.ss_row);
     g.ss_max = g.ss_row * ((g.py - 1) * step + sh + (rw > 0 ? 1 - rh : 1));
     if (rw > 0) {
         g.box_rows = g.h - rh + 1;
-        g.box_pitch = (g.w - rw + 1 + 3) & ~3;
+        g.flag_words = (g.tiles_x * g.tiles_y + 3) / 4;
+        // a row of the image = m planes (same de-interleave as the LDS region) of box_plane words;
+        // the slack lets a tile read whole 16-byte groups past its last column
+        const int m = 1 << g.swz_log2;
+        g.box_plane = ((g.w - rw + 1 + m - 1) / m + 4 + 3) & ~3;
         // one wave yields up to 256 - rw columns (a multiple of 4) of a band of rows; bands are sized so
         // that a batch of a few hundred frames fills the chip once (about 24 waves per frame at VGA)
         const int bw = g.w - rw + 1, ow_max = (kBoxSpan - rw) & ~3;
@@ -533,9 +541,13 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     STEP(dev_alloc(p, &p->hits, (size_t)cap * hits_cap));
     STEP(dev_alloc(p, &p->hit_box, (size_t)cap * hits_cap));
     STEP(dev_alloc(p, &p->hit_rot, (size_t)cap * hits_cap));
-    if (g.uniform) STEP(dev_alloc(p, &p->box, (size_t)cap * g.box_rows * g.box_pitch));
+    if (g.uniform) {
+        const size_t words = (size_t)cap * g.box_rows * ((size_t)g.box_plane << g.swz_log2);
+        STEP(dev_alloc(p, &p->box, words));
+        if (rc == DH_OK && hipMemset(p->box, 0, words * sizeof(uint32_t)) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box)");   // the slack columns stay 0
+    }
     if (p->n_leaves <= DH_LEAF_HIST_MAX && !getenv("DH_NO_LEAF_HIST")) STEP(dev_alloc(p, &p->leaf_hits, (size_t)cap * p->n_leaves));
-    STEP(dev_alloc(p, &p->counters, (size_t)cap * (1 + DH_POSGRID + DH_GRID3)));
+    STEP(dev_alloc(p, &p->counters, (size_t)cap * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words)));
     STEP(dev_alloc(p, &p->ws_poses, cap));
     STEP(dev_alloc(p, &p->ws_midp, (size_t)cap * 3));
     STEP(dev_alloc(p, &p->ws_rot, (size_t)cap * 3));
@@ -550,11 +562,12 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     }
 #undef STEP
     if (rc != DH_OK) { free_workspace(p); return rc; }
-    if (g.npatch > 0 && g.uniform && p->nodes_u_ss != g.ss_row) {     // compact nodes carry LDS offsets for this row stride
-        hipError_t e = dh_launch_nodes_compact(p->dev, g.ss_row, (uint32_t)(p->f_rw * p->f_rh), p->nodes_u, p->own_stream);
+    const long long nkey = ((long long)g.ss_row << 32) | ((long long)g.swz_q << 4) | g.swz_log2;
+    if (g.npatch > 0 && g.uniform && p->nodes_u_key != nkey) {     // compact nodes carry LDS offsets for this row stride
+        hipError_t e = dh_launch_nodes_compact(p->dev, g.ss_row, g.swz_log2, g.swz_q, (uint32_t)(p->f_rw * p->f_rh), p->nodes_u, p->own_stream);
         if (e == hipSuccess) e = hipStreamSynchronize(p->own_stream);
         if (e != hipSuccess) { free_workspace(p); return fail(DH_EHIP, "k_nodes_compact: %s", hipGetErrorString(e)); }
-        p->nodes_u_ss = g.ss_row;
+        p->nodes_u_key = nkey;
     }
     p->geom = g;
     p->cap_frames = cap;
@@ -578,11 +591,17 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     const size_t hoff = (size_t)f0 * p->hits_cap;
     const uint16_t *fr = frames + (size_t)f0 * w * h;
     if (profile) HIP_TRY(hipEventRecord(p->ev[0], s));
-    uint32_t *box = g.uniform ? p->box + (size_t)f0 * g.box_rows * g.box_pitch : nullptr;
+    uint32_t *box = g.uniform ? p->box + (size_t)f0 * g.box_rows * ((size_t)g.box_plane << g.swz_log2) : nullptr;
+    // tile flags: one byte per tile, frames packed back to back (the slice always starts at the frame the memset covered)
+    uint8_t *tile_flags = (uint8_t *)(p->counters + (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3)) + (size_t)f0 * g.tiles_x * g.tiles_y;
     if (g.npatch > 0 && g.uniform) {
         BoxArgs ba{};
         ba.frames = fr; ba.zeros = p->zeros; ba.n_frames = n; ba.w = w; ba.h = h; ba.rw = p->f_rw; ba.rh = p->f_rh;
-        ba.out = box; ba.pitch = g.box_pitch; ba.rows = g.box_rows;
+        ba.tile_flags = tile_flags; ba.tiles_x = g.tiles_x; ba.tiles_y = g.tiles_y;
+        ba.tpx = g.px * (int)p->params.stepwidth; ba.tpy = g.py * (int)p->params.stepwidth;
+        ba.tbw = (g.px - 1) * (int)p->params.stepwidth + (int)p->params.subimage_width - p->f_rw + 1;
+        ba.tbh = (g.py - 1) * (int)p->params.stepwidth + (int)p->params.subimage_height - p->f_rh + 1;
+        ba.out = box; ba.plane = g.box_plane; ba.rows = g.box_rows; ba.lg = g.swz_log2;
         ba.ow = g.box_ow; ba.oh = g.box_oh; ba.parts = g.box_parts; ba.bands = g.box_bands;
         ba.blocks_per_frame = (g.box_parts * g.box_bands + 3) / 4;
         HIP_TRY(dh_launch_boxsum(ba, s));
@@ -594,10 +613,11 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.step = (int)p->params.stepwidth; ta.sw = (int)p->params.subimage_width; ta.sh = (int)p->params.subimage_height;
         ta.lw = ta.sw / 2; ta.lh = ta.sh / 2;
         ta.nx = g.nx; ta.ny = g.ny; ta.px = g.px; ta.py = g.py; ta.tiles_x = g.tiles_x; ta.tiles_y = g.tiles_y;
-        ta.ss_max = g.ss_max; ta.ss_row = g.ss_row;
+        ta.ss_max = g.ss_max; ta.ss_row = g.ss_row; ta.swz_log2 = g.swz_log2; ta.swz_q = g.swz_q;
         ta.uniform = g.uniform ? 1 : 0; ta.rw = p->f_rw; ta.rh = p->f_rh; ta.area = (uint32_t)(p->f_rw * p->f_rh);
         ta.nodes_u = p->nodes_u;
-        ta.box = box; ta.box_pitch = g.box_pitch; ta.box_rows = g.box_rows;
+        ta.box = box; ta.box_plane = g.box_plane; ta.box_rows = g.box_rows;
+        ta.tile_flags = tile_flags;
         if (const char *e = getenv("DH_TRAV_STOP")) ta.stop_phase = atoi(e);
         static unsigned long long *stamps = nullptr;
         if (getenv("DH_TRAV_STAMPS")) {
@@ -680,7 +700,7 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
     mat3_inv_f32(K, kinv);   // cached in a RefCell by the reference (types.rs:436-441)
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
-        HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3) * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3 + (size_t)p->geom.flag_words) * sizeof(uint32_t), s));
         if (p->leaf_hits) HIP_TRY(hipMemsetAsync(p->leaf_hits, 0, (size_t)m * p->n_leaves * sizeof(uint32_t), s));
         const uint16_t *fr = frames + (size_t)f0 * w * h;
         const float *mg = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
@@ -815,6 +835,8 @@ static int aux_run(dh_predictor *p, const uint16_t *frames, int n, int w, int h,
     float kinv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, kid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (K) mat3_inv_f32(K, kinv);
     HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * sizeof(uint32_t), s));   // hit counters only
+    if (p->geom.flag_words)
+        HIP_TRY(hipMemsetAsync(p->counters + (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3), 0, (size_t)p->cap_frames * p->geom.flag_words * sizeof(uint32_t), s));
     HIP_TRY(hipMemsetAsync(p->aux_flags, 0, (size_t)n * std::max(g.npatch, 1), s));
     int rc = enqueue_range(p, frames, 0, n, w, h, K ? K : kid, kinv, nullptr, nullptr, nullptr, p->ws_poses, s, false,
                            p->aux_leaf, p->aux_flags, true);

@@ -90,9 +90,11 @@ struct TraverseArgs {
     int uniform;            // 1: every split rectangle is rw x rh -> box-sum fast path fed by k_boxsum
     int rw, rh;
     uint32_t area;          // rw * rh
-    const uint32_t *box;    // uniform path: [n_frames][box_rows][box_pitch] box-sum images written by k_boxsum
-    int box_pitch, box_rows;
-    const void *nodes_u;    // NodeU[n_nodes], built by k_nodes_compact for this ss_row
+    int swz_log2, swz_q;    // uniform path: LDS slot of region cell (y, x) = y * ss_row + (x & (m - 1)) * swz_q + (x >> swz_log2), m = 1 << swz_log2
+    const uint32_t *box;    // uniform path: [n_frames][box_rows][m planes][box_plane] box-sum images written by k_boxsum
+    int box_plane, box_rows;
+    const uint8_t *tile_flags; // uniform path: [n_frames][tiles] 1 = the tile's region holds a non-zero box sum (k_boxsum)
+    const void *nodes_u;    // NodeU[n_nodes], built by k_nodes_compact for this region layout
     unsigned long long *dbg_stamps; // profiling: [8] summed cycles per phase over all workgroups (env DH_TRAV_STAMPS)
     int stop_phase;         // profiling knob (env DH_TRAV_STOP): 0 = run everything, k = return after phase k
     float kinv[9];
@@ -108,15 +110,18 @@ struct TraverseArgs {
 };
 
 // k_boxsum: per frame the image of all rw x rh rectangle sums, out[y][x] = sum of the rectangle whose
-// top-left pixel is (x, y), for x <= w - rw, y <= h - rh (pitch columns per row, the pad is zeroed).
+// top-left pixel is (x, y), for x <= w - rw, y <= h - rh, columns de-interleaved like k_traverse's LDS region.
 struct BoxArgs {
     const uint16_t *frames;
     const uint16_t *zeros;  // >= 8 zero bytes, 8-byte aligned (stands in for the columns right of the image)
     int n_frames, w, h;
     int rw, rh;
     uint32_t *out;
-    int pitch, rows;        // row stride in words (multiple of 4), rows = h - rh + 1
+    int plane, rows, lg;    // a row is (1 << lg) planes of `plane` words (multiple of 4): column x sits in plane x mod m at x / m; rows = h - rh + 1
     int ow, oh;             // rectangle origins one wave produces: ow columns (multiple of 4, <= 256 - rw) x oh rows
+    uint8_t *tile_flags;    // [n_frames][tiles_x * tiles_y] k_traverse tiles with a non-zero sum in their region; zeroed per batch by the host
+    int tiles_x, tiles_y;   // k_traverse's tiling: tile (tx, ty) reads columns [tx * tpx, tx * tpx + tbw), rows [ty * tpy, ty * tpy + tbh)
+    int tpx, tpy, tbw, tbh;
     int parts, bands;       // waves across / down a frame
     int blocks_per_frame;   // ceil(parts * bands / 4)
 };
@@ -190,7 +195,7 @@ hipError_t dh_launch_mask(const AuxArgs &a, hipStream_t s);
 hipError_t dh_launch_hough2d(const AuxArgs &a, uint16_t *out, hipStream_t s);
 hipError_t dh_kernels_init();
 hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s);
-hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, uint32_t area, void *out, hipStream_t s);
+hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int swz_q, uint32_t area, void *out, hipStream_t s);
 hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s);
 hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s);
 hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s);
@@ -199,3 +204,5 @@ hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s);
 // rw, rh > 0 selects the uniform (box-sum region) layout, 0 the general (SAT) layout
 size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees, int rw, int rh);
 int dh_traverse_row_stride(int px, int step, int sw, int rw);
+// uniform path: column de-interleave factor (log2) for this stride of window positions, plane size, padded row stride
+void dh_traverse_swizzle(int px, int step, int sw, int rw, int *swz_log2, int *swz_q, int *ss_row);

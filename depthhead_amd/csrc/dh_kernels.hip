@@ -201,7 +201,7 @@ struct __attribute__((aligned(16))) NodeU {
     int32_t  child_one;
 };
 
-__global__ void __launch_bounds__(256) k_nodes_compact(const dh_node *nodes, uint32_t n, int ss, uint32_t area, NodeU *out) {
+__global__ void __launch_bounds__(256) k_nodes_compact(const dh_node *nodes, uint32_t n, int ss, int swz_log2, int swz_q, uint32_t area, NodeU *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     dh_node nd = nodes[i];
@@ -222,7 +222,9 @@ __global__ void __launch_bounds__(256) k_nodes_compact(const dh_node *nodes, uin
         amb = (uint32_t)(h - l - 1);                            // 0..2
     }
     NodeU o;
-    uint32_t o1 = (uint32_t)nd.r1[1] * (uint32_t)ss + nd.r1[0], o2 = (uint32_t)nd.r2[1] * (uint32_t)ss + nd.r2[0];
+    const uint32_t mm = (1u << swz_log2) - 1u;       // region slot of the rectangle's top-left cell (dh_traverse_swizzle)
+    uint32_t o1 = (uint32_t)nd.r1[1] * (uint32_t)ss + (nd.r1[0] & mm) * (uint32_t)swz_q + (nd.r1[0] >> swz_log2);
+    uint32_t o2 = (uint32_t)nd.r2[1] * (uint32_t)ss + (nd.r2[0] & mm) * (uint32_t)swz_q + (nd.r2[0] >> swz_log2);
     o.offs = o1 | (o2 << 14) | (amb << 28);
     o.ilo = ilo;
     o.child_zero = nd.child_zero;
@@ -230,9 +232,9 @@ __global__ void __launch_bounds__(256) k_nodes_compact(const dh_node *nodes, uin
     out[i] = o;
 }
 
-hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, uint32_t area, void *out, hipStream_t s) {
+hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int swz_q, uint32_t area, void *out, hipStream_t s) {
     if (f.n_nodes == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_nodes_compact, dim3((f.n_nodes + 255) / 256), dim3(256), 0, s, f.nodes, f.n_nodes, ss, area, (NodeU *)out);
+    hipLaunchKernelGGL(k_nodes_compact, dim3((f.n_nodes + 255) / 256), dim3(256), 0, s, f.nodes, f.n_nodes, ss, swz_log2, swz_q, area, (NodeU *)out);
     return hipGetLastError();
 }
 
@@ -250,12 +252,39 @@ hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, uint32_t area, vo
 #define TRAV_WAVES (TRAV_THREADS / WAVE)
 #define ROWS_IN_FLIGHT 8
 
-// Row stride of the LDS image one tile works on.  General path: the (fw + 1)-column SAT with an odd
-// stride (row-per-lane passes are bank-conflict free).  Uniform path (rw > 0): the box-sum region of
-// fw - rw + 1 columns, padded to a multiple of 4 words so that rows are copied with 16-byte accesses.
+// LDS image one tile works on.
+// General path: the (fw + 1)-column SAT with an odd row stride (row-per-lane passes are
+// bank-conflict free).
+// Uniform path (rw > 0): the box-sum region of bw = fw - rw + 1 columns.  All lanes of a wave sit at
+// the same tree node most of the time, so they read region cells that differ only by their
+// windows' origins: `step` columns apart along a row of windows, step * ss apart between rows.
+// With step = 4 a linear layout would use 16 of the 64 LDS banks.  The columns are therefore
+// de-interleaved by m = the largest power of two dividing step (at most 8): cell (y, x) lives at
+// y * ss + (x mod m) * q + x / m with q = ceil(bw / m) rounded up to a multiple of 4.  Window origins are multiples of m, so the
+// slot of (origin + rectangle offset) is still base(origin) + offset(rectangle), neighbouring
+// windows are step / m (odd) slots apart, and the row stride ss >= m * q is padded so that the
+// rows of windows a wave spans land on different banks.
+void dh_traverse_swizzle(int px, int step, int sw, int rw, int *swz_log2, int *swz_q, int *ss_row) {
+    const int bw = (px - 1) * step + sw - rw + 1;
+    int lg = 0;
+    while (lg < 3 && (step & (1 << lg)) == 0) ++lg;
+    const int m = 1 << lg, q = ((bw + m - 1) / m + 3) & ~3;     // planes start on 16-byte boundaries
+    int best_pad = 0;
+    long best_cost = -1;
+    for (int pad = 0; pad < 32; pad += 4) {                         // rows too
+        // bank histogram of the 64 lanes of a wave reading the same rectangle for consecutive windows
+        const int ss = m * q + pad;
+        int cnt[64] = {0};
+        for (int i = 0; i < 64; ++i) cnt[((i / px) * step * ss + (i % px) * (step / m)) & 63]++;
+        long cost = 0;
+        for (int b = 0; b < 64; ++b) cost += (long)cnt[b] * cnt[b];
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_pad = pad; }
+    }
+    *swz_log2 = lg; *swz_q = q; *ss_row = m * q + best_pad;
+}
 int dh_traverse_row_stride(int px, int step, int sw, int rw) {
-    const int fw = (px - 1) * step + sw;
-    return rw > 0 ? (fw - rw + 1 + 3) & ~3 : (fw + 1) | 1;
+    if (rw > 0) { int lg, q, ss; dh_traverse_swizzle(px, step, sw, rw, &lg, &q, &ss); return ss; }
+    return ((px - 1) * step + sw + 1) | 1;
 }
 size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees, int rw, int rh) {
     size_t fh = (size_t)(py - 1) * step + sh;
@@ -263,6 +292,16 @@ size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_tre
     size_t rows = rw > 0 ? fh - rh + 1 : fh + 1;
     size_t npt = (size_t)px * py;
     return (ss * rows + npt * n_trees + npt * 3 + npt * 2 + 16) * 4;   // keep in step with the carve-up in k_traverse
+}
+
+// n / d for 0 <= n < 2^22 and d >= 1, given rd = 1.0f / d: the float estimate is off by at most one
+// (relative error < 2^-22), which one correction step repairs.  Replaces the ~35-instruction integer
+// division sequence in per-lane index arithmetic.
+__device__ __forceinline__ int div_small(int n, int d, float rd) {
+    int q = (int)((float)n * rd);
+    const int r = n - q * d;
+    q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+    return q;
 }
 
 // Inclusive prefix sum across the 64 lanes of a wave in six DPP adds (no LDS, no barrier):
@@ -537,7 +576,7 @@ __device__ __forceinline__ bool sat_passes(uint32_t *sat, uint32_t *flag, const 
 // image); RW4: rw % 4 == 0 (the shifted prefix is read back with one 16-byte LDS load).  Both are
 // uniform, and compile-time here so that the loads of a group stay straight-line code.
 template <bool AL, bool RW4, int RIF>
-__device__ __forceinline__ void boxsum_wave(const BoxArgs &a, const uint16_t *img, uint32_t *pex, uint32_t *out,
+__device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const uint16_t *img, uint32_t *pex, uint32_t *out,
                                             int lane, int x, int Y0, int y_end, bool store) {
     // Columns right of the image read a.zeros with row stride 0 instead of being masked, so every
     // load is unconditional and nothing has to wait for it before its use.
@@ -556,7 +595,14 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, const uint16_t *im
     // warm-up steps the "leaving" loads fetch row Y0 and are ignored).
     const int nsteps = (a.rh - 1) + (y_end - Y0), warm = a.rh - 1;
     const uint32_t *pex_rd = pex + 4 * lane + a.rw;
-    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    // output slots of this lane's four columns within a row: plane (x mod m), position x / m
+    const int mm = (1 << a.lg) - 1;
+    const size_t row_pitch = (size_t)a.plane << a.lg;
+    const int o0 = (x & mm) * a.plane + (x >> a.lg), o1 = ((x + 1) & mm) * a.plane + ((x + 1) >> a.lg);
+    const int o2 = ((x + 2) & mm) * a.plane + ((x + 2) >> a.lg), o3 = ((x + 3) & mm) * a.plane + ((x + 3) >> a.lg);
+    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, acc = 0;
+    uint8_t *flags = a.tile_flags + (size_t)frame * a.tiles_x * a.tiles_y;
+    const float r_tpx = 1.0f / (float)a.tpx, r_tpy = 1.0f / (float)a.tpy;
     uint2 e[RIF], l[RIF], en[RIF], ln[RIF];
 #pragma unroll
     for (int k = 0; k < RIF; ++k) {
@@ -586,8 +632,28 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, const uint16_t *im
             uint4 r;
             if (RW4) r = *(const uint4 *)__builtin_assume_aligned(pex_rd, 16);
             else r = make_uint4(pex_rd[0], pex_rd[1], pex_rd[2], pex_rd[3]);
-            if (store) *(uint4 *)(out + (size_t)(Y0 + t - warm) * a.pitch) = make_uint4(r.x - pe.x, r.y - pe.y, r.z - pe.z, r.w - pe.w);
+            if (store) {
+                acc |= (r.x - pe.x) | (r.y - pe.y) | (r.z - pe.z) | (r.w - pe.w);
+                uint32_t *orow = out + (size_t)(Y0 + t - warm) * row_pitch;
+                if (a.lg == 0) *(uint4 *)(orow + o0) = make_uint4(r.x - pe.x, r.y - pe.y, r.z - pe.z, r.w - pe.w);
+                else { orow[o0] = r.x - pe.x; orow[o1] = r.y - pe.y; orow[o2] = r.z - pe.z; orow[o3] = r.w - pe.w; }
+            }
             v0 -= l[k].x & 0xffffu; v1 -= l[k].x >> 16; v2 -= l[k].y & 0xffffu; v3 -= l[k].y >> 16;
+            // Which k_traverse tiles have a non-zero rectangle sum in their region?  Every 32 output rows
+            // (and at the end of the band) each lane that saw a non-zero sum marks the tiles whose regions
+            // contain its columns and those rows (plain stores of 1: the flags are zeroed per batch).
+            const int yo = Y0 + t - warm;
+            if ((yo & 31) == 31 || yo == y_end - 1) {
+                if (acc != 0) {
+                    // tile tx covers columns [tx * tpx, tx * tpx + tbw): tx in [(x + 3 - tbw) / tpx + 1 .. x / tpx] clipped
+                    const int y_lo = max(yo & ~31, Y0);
+                    const int tx1 = min(div_small(x + 3, a.tpx, r_tpx), a.tiles_x - 1), tx0 = max(x - a.tbw < 0 ? 0 : div_small(x - a.tbw, a.tpx, r_tpx) + 1, 0);
+                    const int ty1 = min(div_small(yo, a.tpy, r_tpy), a.tiles_y - 1), ty0 = max(y_lo - a.tbh + 1 <= 0 ? 0 : div_small(y_lo - a.tbh, a.tpy, r_tpy) + 1, 0);
+                    for (int ty = ty0; ty <= ty1; ++ty)
+                        for (int tx = tx0; tx <= tx1; ++tx) flags[ty * a.tiles_x + tx] = 1;
+                }
+                acc = 0;
+            }
         }
 #pragma unroll
         for (int k = 0; k < RIF; ++k) { e[k] = en[k]; l[k] = ln[k]; }
@@ -597,31 +663,30 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, const uint16_t *im
 __global__ void __launch_bounds__(BOXW_THREADS) k_boxsum(BoxArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t pex_s[BOXW_WAVES][BOX_SPAN + BOX_MAXR + 8];
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;      // same frame -> XCD mapping as k_traverse
-    const int frame = (j / a.blocks_per_frame) * 8 + xcd;
-    const int unit = (j % a.blocks_per_frame) * BOXW_WAVES + wv;
+    const int frame = (int)blockIdx.z * 8 + (int)blockIdx.x;     // grid (8, blocks per frame, frames / 8): same frame -> XCD mapping as k_traverse
+    const int unit = (int)blockIdx.y * BOXW_WAVES + wv;
     if (frame >= a.n_frames || unit >= a.bands * a.parts) return;      // waves are independent: no barriers below
-    const int band = unit / a.parts, part = unit - band * a.parts;
+    const int band = div_small(unit, a.parts, 1.0f / (float)a.parts), part = unit - band * a.parts;
     const int X0 = part * a.ow, Y0 = band * a.oh;           // X0 % 4 == 0 (host)
     const int y_end = min(Y0 + a.oh, a.rows);
     if (Y0 >= a.rows) return;
     const int x = X0 + 4 * lane;                            // this lane's columns x .. x + 3
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
-    const bool store = 4 * lane < a.ow && x < a.pitch;      // pad columns [w - rw + 1, pitch) get clipped-rectangle sums
+    const bool store = 4 * lane < a.ow && x + 3 < (a.plane << a.lg);   // columns right of w - rw get clipped-rectangle sums or stay 0
     uint32_t *pex = pex_s[wv];
-    uint32_t *out = a.out + (size_t)frame * a.rows * a.pitch + x;
+    uint32_t *out = a.out + (size_t)frame * a.rows * ((size_t)a.plane << a.lg);
     const bool al = (a.w & 3) == 0 && (((size_t)a.frames) & 7) == 0, rw4 = (a.rw & 3) == 0;
-    if (al && rw4) boxsum_wave<true, true, BOX_ROWS_IN_FLIGHT>(a, img, pex, out, lane, x, Y0, y_end, store);
-    else if (al) boxsum_wave<true, false, BOX_ROWS_IN_FLIGHT>(a, img, pex, out, lane, x, Y0, y_end, store);
-    else if (rw4) boxsum_wave<false, true, 1>(a, img, pex, out, lane, x, Y0, y_end, store);
-    else boxsum_wave<false, false, 1>(a, img, pex, out, lane, x, Y0, y_end, store);
+    if (al && rw4) boxsum_wave<true, true, BOX_ROWS_IN_FLIGHT>(a, frame, img, pex, out, lane, x, Y0, y_end, store);
+    else if (al) boxsum_wave<true, false, BOX_ROWS_IN_FLIGHT>(a, frame, img, pex, out, lane, x, Y0, y_end, store);
+    else if (rw4) boxsum_wave<false, true, 1>(a, frame, img, pex, out, lane, x, Y0, y_end, store);
+    else boxsum_wave<false, false, 1>(a, frame, img, pex, out, lane, x, Y0, y_end, store);
 }
 
 hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s) {
-    const int frames8 = (a.n_frames + 7) / 8 * 8;
-    const int grid = frames8 * a.blocks_per_frame;
-    if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_boxsum, dim3(grid), dim3(BOXW_THREADS), 0, s, a);
+    const int fb = (a.n_frames + 7) / 8;
+    if (fb == 0 || a.blocks_per_frame == 0) return hipSuccess;
+    if (a.blocks_per_frame > 65535 || fb > 65535) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_boxsum, dim3(8, a.blocks_per_frame, fb), dim3(BOXW_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
@@ -634,6 +699,7 @@ __device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32
                                              int n_active, int total, int cx, int ss, int T) {
     const int tid = threadIdx.x;
     const NodeU *nodes_u = (const NodeU *)a.nodes_u;
+    const float r_active = 1.0f / (float)n_active, r_cx = 1.0f / (float)cx;
     for (int k0 = tid; k0 < total; k0 += W * TRAV_THREADS) {
         int cur[W], dst[W];
         const uint32_t *sp[W];
@@ -642,10 +708,10 @@ __device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32
             const int k = k0 + i * TRAV_THREADS;
             const bool has = k < total;
             const int kk = has ? k : k0;
-            const int t = kk / n_active, slot = kk - t * n_active;
+            const int t = div_small(kk, n_active, r_active), slot = kk - t * n_active;
             const int p = (int)active[slot];
-            const int py = p / cx, px = p - py * cx;
-            sp[i] = sat + py * a.step * ss + px * a.step;
+            const int py = div_small(p, cx, r_cx), px = p - py * cx;
+            sp[i] = sat + py * a.step * ss + ((px * a.step) >> a.swz_log2);   // window origins are multiples of m
             dst[i] = p * T + t;
             cur[i] = has ? a.f.roots[t] : -1;
         }
@@ -693,20 +759,21 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
 
     // XCD-aware block -> (frame, tile): blocks b and b+8 share an XCD (and its L2), so one XCD
     // walks whole frames and the overlapping tile halos of a frame are re-read from one L2.
-    const int tiles = a.tiles_x * a.tiles_y;
-    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int frame = (j / tiles) * 8 + xcd;
-    const int tile = j % tiles;
+    // The grid is (8, tiles, frames / 8): the linear workgroup id -- which the hardware deals out to the
+    // XCDs round-robin -- is x + 8 * (tile + tiles * z), so no division is needed to decode it.
+    const int frame = (int)blockIdx.z * 8 + (int)blockIdx.x;
+    const int tile = (int)blockIdx.y;
     if (frame >= a.n_frames || a.stop_phase == 9) return;
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int ty = div_small(tile, a.tiles_x, 1.0f / (float)a.tiles_x), tx = tile - ty * a.tiles_x;
     const int cx = min(a.px, a.nx - tx * a.px), cy = min(a.py, a.ny - ty * a.py);
+    const float r_cx = 1.0f / (float)cx;
     const int npt = cx * cy;
     const int fx0 = tx * a.px * a.step, fy0 = ty * a.py * a.step;   // footprint origin (pixels)
     const int fw = (cx - 1) * a.step + a.sw, fh = (cy - 1) * a.step + a.sh;
     const int ss = a.ss_row;
 
     uint32_t *sat = lds;
-    int32_t *leaf = (int32_t *)(lds + a.ss_max);
+    int32_t *leaf = (int32_t *)(sat + a.ss_max);
     float *p3s = (float *)(leaf + a.px * a.py * T);
     uint32_t *active = (uint32_t *)(p3s + a.px * a.py * 3);
     uint32_t *pres = active + a.px * a.py;   // per active slot: hit base | gated << 31
@@ -714,63 +781,58 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
 
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
     unsigned long long t_prev = a.dbg_stamps ? clock64() : 0ull;
-    // depth at the centre of this thread's window (phase 2), requested now so that its latency
-    // hides behind phase 1
+    // depth at the centre of this thread's window (phase 2), requested at the start of phase 1 so
+    // that its latency hides behind it
     uint16_t zc = 0;
-    if (tid < npt) zc = img[(size_t)(fy0 + (tid / cx) * a.step + a.lh) * a.w + fx0 + (tid % cx) * a.step + a.lw];
 
     // ---- phase 1.  General path: summed-area table of the footprint, modulo 2^32 (footprints of up
     // to 128 x 128 and 256 x 64 pixels are scanned in registers with DPP wave scans, anything else
     // takes the pass-based build).  Uniform path: copy the tile's region of the frame's box-sum image
-    // (k_boxsum): slot (y, x) = sum of the rw x rh rectangle whose top-left pixel is (fx0 + x, fy0 + y).
+    // (k_boxsum): cell (y, x) = sum of the rw x rh rectangle whose top-left pixel is (fx0 + x, fy0 + y).
+    // this thread's window (one per thread: npt <= 1024) and the depth at its centre
+    const int wy = div_small(tid, cx, r_cx), wx = tid - wy * cx;
+    if (tid < npt) zc = img[(size_t)(fy0 + wy * a.step + a.lh) * a.w + fx0 + wx * a.step + a.lw];
+    bool nonzero = true;
+    if (UNI) {
+        // k_boxsum flagged the tiles whose region holds a non-zero rectangle sum; any other tile has only
+        // background windows and leaves before copying anything
+        nonzero = a.tile_flags[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] != 0;
+    }
     if (tid < 8) misc[tid] = 0;
     __syncthreads();
-    bool nonzero;
-    if (UNI) {
-        const int bw = fw - a.rw + 1, bh = fh - a.rh + 1;
-        const uint32_t *bx = a.box + ((size_t)frame * a.box_rows + fy0) * a.box_pitch + fx0;
-        uint32_t any = 0;
-        const int q4 = (bw + 3) >> 2;                 // 16-byte groups per row; ss >= 4 * q4 by construction
-        if ((fx0 & 3) == 0 && q4 <= WAVE) {
-            // lanes-per-row = next power of two >= q4: a wave copies 64 / lpr rows per pass with one
-            // 16-byte load and one 16-byte LDS store per lane; four passes are in flight per lane.
-            int sh_l = 0;
-            while ((1 << sh_l) < q4) ++sh_l;
-            const int rpw = WAVE >> sh_l, rpp = rpw * TRAV_WAVES;
-            const int lr = lane >> sh_l, lx = lane & ((1 << sh_l) - 1);
-            const bool colok = lx < q4;
-            for (int y0 = (tid >> 6) * rpw + lr; y0 < bh; y0 += 4 * rpp) {
-                uint4 v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int y = y0 + k * rpp;
-                    const bool ok = colok && y < bh;
-                    v[k] = *(const uint4 *)(bx + (ok ? (size_t)y * a.box_pitch + 4 * lx : (size_t)0));
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int y = y0 + k * rpp;
-                    if (colok && y < bh) {
-                        *(uint4 *)(sat + y * ss + 4 * lx) = v[k];
-                        any |= v[k].x | v[k].y | v[k].z | v[k].w;
-                    }
-                }
-            }
+    if (UNI && nonzero) {
+        // The frame's box-sum image is stored with the same column de-interleave as the LDS region
+        // (row = m planes of box_plane words; plane c holds the columns = c mod m), so a region row is
+        // m runs of q consecutive words and is copied by ONE direct-to-LDS load of 16 bytes per lane
+        // (no registers, no LDS-store instructions) whenever the tile's first column sits on a
+        // 16-byte boundary of its plane -- the host picks px % 4 == 0 for that.
+        const int bh = fh - a.rh + 1, bw = fw - a.rw + 1;
+        const int m = 1 << a.swz_log2, q = a.swz_q, X0 = fx0 >> a.swz_log2;      // fx0 is a multiple of m
+        const uint32_t *bx = a.box + ((size_t)frame * a.box_rows + fy0) * ((size_t)a.box_plane << a.swz_log2) + X0;
+        const int pieces = (m * q) >> 2;                                          // 16-byte pieces per region row
+        if ((X0 & 3) == 0 && pieces <= WAVE) {
+            const int q4 = q >> 2;
+            const int c = (lane * (65536 / q4 + 1)) >> 16, g = lane - c * q4;      // piece -> (plane, group); exact for lane < 64
+            const uint32_t *src = bx + (size_t)c * a.box_plane + 4 * g;
+            const size_t row_pitch = (size_t)a.box_plane << a.swz_log2;
+            if (lane < pieces)
+                for (int y = tid >> 6; y < bh; y += TRAV_WAVES)
+                    __builtin_amdgcn_global_load_lds(src + (size_t)y * row_pitch, sat + y * ss, 16, 0, 0);
         } else {
-            const int q = TRAV_THREADS / bw, r = TRAV_THREADS - q * bw;
+            const int qd = TRAV_THREADS / bw, rd = TRAV_THREADS - qd * bw;
             int yy = tid / bw, xx = tid - yy * bw;
+            const int mm = m - 1;
             while (yy < bh) {
-                const uint32_t v = bx[(size_t)yy * a.box_pitch + xx];
-                sat[yy * ss + xx] = v;
-                any |= v;
-                yy += q; xx += r;
+                const int xg = fx0 + xx;
+                sat[yy * ss + (xx & mm) * q + (xx >> a.swz_log2)] =
+                    a.box[((size_t)frame * a.box_rows + fy0 + yy) * ((size_t)a.box_plane << a.swz_log2) + (size_t)(xg & mm) * a.box_plane + (xg >> a.swz_log2)];
+                yy += qd; xx += rd;
                 if (xx >= bw) { xx -= bw; ++yy; }
             }
         }
-        if (__ballot(any != 0) != 0ull && lane == 0) misc[4] = 1;
         __syncthreads();
-        nonzero = misc[4] != 0;
-    } else {
+    }
+    if (!UNI) {
         const int strip = (fh + TRAV_WAVES - 1) / TRAV_WAVES;
         if (fw <= 2 * WAVE && strip <= 8) nonzero = sat_rows_dpp<2>(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
         else if (fw <= 4 * WAVE && strip <= 4) nonzero = sat_rows_dpp<4>(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
@@ -798,7 +860,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // ---- phase 2: per patch: centre -> 3-D (prediction.rs:551-554), background gate (:567-571)
     if (tid < npt) {                                                   // npt <= 1024: one window per thread
         const int p = tid;
-        int pxi = p % cx, pyi = p / cx;
+        const int pxi = wx, pyi = wy;
         int ox = pxi * a.step, oy = pyi * a.step;                      // patch origin inside the footprint
         uint32_t sum;
         if (UNI) {
@@ -807,8 +869,11 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             // when every one of those rectangle sums is
             sum = 0;
             for (int cyk = 0; cyk < a.sh; cyk += a.rh) {
-                const uint32_t *rowp = sat + (oy + min(cyk, a.sh - a.rh)) * ss + ox;
-                for (int cxk = 0; cxk < a.sw; cxk += a.rw) sum |= rowp[min(cxk, a.sw - a.rw)];
+                const uint32_t *rowp = sat + (oy + min(cyk, a.sh - a.rh)) * ss;
+                for (int cxk = 0; cxk < a.sw; cxk += a.rw) {
+                    const int xc = ox + min(cxk, a.sw - a.rw);
+                    sum |= rowp[(xc & ((1 << a.swz_log2) - 1)) * a.swz_q + (xc >> a.swz_log2)];
+                }
             }
         } else {
             sum = sat[(oy + a.sh) * ss + ox + a.sw] - sat[oy * ss + ox + a.sw] - sat[(oy + a.sh) * ss + ox] + sat[oy * ss + ox];
@@ -854,9 +919,9 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         else walk_uniform<4>(a, sat, leaf, active, n_active, total, cx, ss, T);
     } else {
         for (int k = tid; k < total; k += TRAV_THREADS) {
-            const int t = k / n_active, slot = k - t * n_active;
+            const int t = div_small(k, n_active, 1.0f / (float)n_active), slot = k - t * n_active;
             const int p = (int)active[slot];
-            const int pyi = p / cx, pxi = p - pyi * cx;
+            const int pyi = div_small(p, cx, r_cx), pxi = p - pyi * cx;
             const uint32_t *sp = sat + pyi * a.step * ss + pxi * a.step;
             int cur = a.f.roots[t];
             while (cur >= 0) {
@@ -884,12 +949,13 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // The SAT / box image is dead now; its LDS is reused as scratch for the (patch, tree) pairs so
     // that every dependent global load of this phase is issued by a different thread.
     const int pairs = n_active * T;
+    const float r_T = 1.0f / (float)T;
     double *sprob = (double *)sat;                       // [pairs]
     uint32_t *sflag = (uint32_t *)(sprob + pairs);       // [pairs]
     const bool fits = (size_t)pairs * 12 <= (size_t)a.ss_max * 4;
     if (fits) {
         for (int i = tid; i < pairs; i += TRAV_THREADS) {
-            const int slot = i / T, t = i - slot * T;
+            const int slot = div_small(i, T, r_T), t = i - slot * T;
             const uint32_t lid = (uint32_t)leaf[(int)active[slot] * T + t];
             sprob[i] = a.f.leaf_prob[lid];
             sflag[i] = a.f.leaf_flags[lid];
@@ -924,7 +990,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         HitBox *dbox = a.hit_box + (size_t)frame * a.hits_cap;
         HitRot *drot = a.hit_rot + (size_t)frame * a.hits_cap;
         for (int i = tid; i < pairs; i += TRAV_THREADS) {
-            const int slot = i / T, t = i - slot * T;
+            const int slot = div_small(i, T, r_T), t = i - slot * T;
             const uint32_t pr = pres[slot], lf = sflag[i];
             if (!(pr & 0x80000000u) || !((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF)))) continue;
             uint32_t o = misc[3] + (pr & 0x7fffffffu);
@@ -1017,11 +1083,12 @@ hipError_t dh_kernels_init() {
 }
 
 hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s) {
-    int frames8 = (a.n_frames + 7) / 8 * 8;
-    int grid = frames8 * a.tiles_x * a.tiles_y;
-    if (grid == 0) return hipSuccess;
-    if (a.uniform) hipLaunchKernelGGL(k_traverse<true>, dim3(grid), dim3(TRAV_THREADS), lds_bytes, s, a);
-    else hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(TRAV_THREADS), lds_bytes, s, a);
+    const int tiles = a.tiles_x * a.tiles_y, fb = (a.n_frames + 7) / 8;
+    if (tiles == 0 || fb == 0) return hipSuccess;
+    if (tiles > 65535 || fb > 65535) return hipErrorInvalidConfiguration;
+    const dim3 grid(8, tiles, fb);
+    if (a.uniform) hipLaunchKernelGGL(k_traverse<true>, grid, dim3(TRAV_THREADS), lds_bytes, s, a);
+    else hipLaunchKernelGGL(k_traverse<false>, grid, dim3(TRAV_THREADS), lds_bytes, s, a);
     return hipGetLastError();
 }
 
