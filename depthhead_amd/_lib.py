@@ -34,7 +34,8 @@ class Params(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("traverse_ms", C.c_float), ("vote_ms", C.c_float), ("cluster_ms", C.c_float),
-                ("total_ms", C.c_float), ("n_frames", C.c_uint32), ("boxsum_ms", C.c_float)]
+                ("total_ms", C.c_float), ("n_frames", C.c_uint32), ("boxsum_ms", C.c_float),
+                ("emit_ms", C.c_float), ("reserved", C.c_uint32)]
 
 
 # every symbol include/depthhead_hip.h declares

@@ -183,6 +183,7 @@ struct Geom {
     int px = 0, py = 0, tiles_x = 0, tiles_y = 0, ss_max = 0, ss_row = 0, swz_log2 = 0, swz_q = 0;
     bool uniform = false;       // uniform-rectangle path: k_boxsum feeds k_traverse<true>
     int flag_words = 0;                // per frame: u32 words holding one flag byte per tile (uniform path)
+    int win_cap = 0;                   // slots of a frame's window list: tiles * px * py
     int box_plane = 0, box_rows = 0, box_ow = 0, box_oh = 0, box_parts = 0, box_bands = 0;
     size_t lds = 0;
 };
@@ -248,6 +249,8 @@ struct dh_predictor {
     HitBox *hit_box = nullptr;
     HitRot *hit_rot = nullptr;
     uint32_t *box = nullptr;         // [cap][box_rows][m][box_plane] rectangle-sum images (uniform path)
+    uint32_t *win_patch = nullptr;   // [cap][win_cap] window list: position in the window grid
+    int32_t *win_leaf = nullptr;     // [cap][T][win_cap] window list: leaf per tree
     uint32_t *leaf_hits = nullptr;   // [cap][n_leaves] rotation-vote histogram, only for forests of <= DH_LEAF_HIST_MAX leaves
     uint32_t hits_cap = 0;
     uint32_t *counters = nullptr;    // [n] hit_count | [n][400] pos_grid | [n][8000] rot_grid (one memset)
@@ -280,7 +283,7 @@ struct dh_predictor {
     const uint16_t *last_frames = nullptr;
     // profiling
     bool profiling = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // start, traverse end, vote end, cluster end, boxsum end
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start, emit end, vote end, cluster end, boxsum end, traverse end
     bool ev_valid = false;
 };
 
@@ -330,11 +333,11 @@ static int build_kernel_table(dh_predictor *p) {
 }
 
 static void free_workspace(dh_predictor *p) {
-    void *ptrs[] = {p->box, p->leaf_hits, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
+    void *ptrs[] = {p->box, p->win_patch, p->win_leaf, p->leaf_hits, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
                     p->dbg_flags, p->dbg_guess, p->dbg_trace, p->dbg_steps, p->dbg_votes, p->dbg_vcount};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    p->box = nullptr; p->leaf_hits = nullptr;
+    p->box = nullptr; p->win_patch = nullptr; p->win_leaf = nullptr; p->leaf_hits = nullptr;
     p->aux_leaf = nullptr; p->aux_flags = nullptr; p->aux_u32 = nullptr; p->aux_out = nullptr; p->aux_out_bytes = 0; p->aux_cap = 0;
     p->ws_frames = nullptr; p->hits = nullptr; p->hit_box = nullptr; p->hit_rot = nullptr; p->counters = nullptr; p->ws_poses = nullptr; p->ws_midp = nullptr;
     p->ws_rot = nullptr; p->ws_mask = nullptr; p->dbg_leaf = nullptr; p->dbg_flags = nullptr; p->dbg_guess = nullptr;
@@ -489,6 +492,7 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
     }
     g.tiles_x = (g.nx + g.px - 1) / g.px;
     g.tiles_y = (g.ny + g.py - 1) / g.py;
+    g.win_cap = g.tiles_x * g.tiles_y * g.px * g.py;
     g.ss_row = dh_traverse_row_stride(g.px, step, sw, rw);
     if (rw > 0) dh_traverse_swizzle(g.px, step, sw, rw, &g.swz_log2, &g.swz_q, &g.ss_row);
     g.ss_max = g.ss_row * ((g.py - 1) * step + sh + (rw > 0 ? 1 - rh : 1));
@@ -541,13 +545,15 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     STEP(dev_alloc(p, &p->hits, (size_t)cap * hits_cap));
     STEP(dev_alloc(p, &p->hit_box, (size_t)cap * hits_cap));
     STEP(dev_alloc(p, &p->hit_rot, (size_t)cap * hits_cap));
+    STEP(dev_alloc(p, &p->win_patch, (size_t)cap * std::max(g.win_cap, 1)));
+    STEP(dev_alloc(p, &p->win_leaf, (size_t)cap * std::max(g.win_cap, 1) * p->n_trees));
     if (g.uniform) {
         const size_t words = (size_t)cap * g.box_rows * ((size_t)g.box_plane << g.swz_log2);
         STEP(dev_alloc(p, &p->box, words));
         if (rc == DH_OK && hipMemset(p->box, 0, words * sizeof(uint32_t)) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box)");   // the slack columns stay 0
     }
     if (p->n_leaves <= DH_LEAF_HIST_MAX && !getenv("DH_NO_LEAF_HIST")) STEP(dev_alloc(p, &p->leaf_hits, (size_t)cap * p->n_leaves));
-    STEP(dev_alloc(p, &p->counters, (size_t)cap * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words)));
+    STEP(dev_alloc(p, &p->counters, (size_t)cap * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words + (size_t)g.tiles_x * g.tiles_y)));
     STEP(dev_alloc(p, &p->ws_poses, cap));
     STEP(dev_alloc(p, &p->ws_midp, (size_t)cap * 3));
     STEP(dev_alloc(p, &p->ws_rot, (size_t)cap * 3));
@@ -633,13 +639,29 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         }
         memcpy(ta.kinv, kinv, 9 * sizeof(float));
         ta.f = p->dev;
-        ta.hits = p->hits + hoff; ta.hit_box = p->hit_box + hoff; ta.hit_rot = p->hit_rot + hoff;
-        ta.hit_count = hit_count; ta.hits_cap = p->hits_cap;
-        ta.leaf_hits = (p->leaf_hits && !traverse_only) ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
+        const int tiles = g.tiles_x * g.tiles_y;
+        uint32_t *win_count = p->counters + (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words) + (size_t)f0 * tiles;
+        ta.win_count = win_count; ta.win_cap = g.win_cap;
+        ta.win_patch = p->win_patch + (size_t)f0 * g.win_cap; ta.win_leaf = p->win_leaf + (size_t)f0 * g.win_cap * p->n_trees;
         ta.dbg_leaf = leaf_out ? leaf_out : p->debug ? p->dbg_leaf + (size_t)f0 * g.npatch * p->n_trees : nullptr;
         ta.dbg_flags = flags_out ? flags_out : p->debug ? p->dbg_flags + (size_t)f0 * g.npatch : nullptr;
         HIP_TRY(dh_launch_traverse(ta, g.lds, s));
-    }
+        if (profile) HIP_TRY(hipEventRecord(p->ev[5], s));
+        if (!traverse_only) {
+            EmitArgs ea{};
+            ea.frames = fr; ea.n_frames = n; ea.w = w; ea.h = h;
+            ea.step = ta.step; ea.lw = ta.lw; ea.lh = ta.lh; ea.nx = g.nx; ea.npatch = g.npatch;
+            ea.px = g.px; ea.py = g.py; ea.tiles = tiles;
+            memcpy(ea.kinv, kinv, 9 * sizeof(float));
+            ea.f = p->dev;
+            ea.win_count = win_count; ea.win_patch = ta.win_patch; ea.win_leaf = ta.win_leaf; ea.win_cap = g.win_cap;
+            ea.hits = p->hits + hoff; ea.hit_box = p->hit_box + hoff; ea.hit_rot = p->hit_rot + hoff;
+            ea.hit_count = hit_count; ea.hits_cap = p->hits_cap;
+            ea.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
+            ea.dbg_flags = ta.dbg_flags;
+            HIP_TRY(dh_launch_emit(ea, s));
+        }
+    } else if (profile) HIP_TRY(hipEventRecord(p->ev[5], s));
     if (profile) HIP_TRY(hipEventRecord(p->ev[1], s));
     if (traverse_only) return DH_OK;
     {
@@ -700,7 +722,7 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
     mat3_inv_f32(K, kinv);   // cached in a RefCell by the reference (types.rs:436-441)
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
-        HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3 + (size_t)p->geom.flag_words) * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3 + (size_t)p->geom.flag_words + (size_t)p->geom.tiles_x * p->geom.tiles_y) * sizeof(uint32_t), s));
         if (p->leaf_hits) HIP_TRY(hipMemsetAsync(p->leaf_hits, 0, (size_t)m * p->n_leaves * sizeof(uint32_t), s));
         const uint16_t *fr = frames + (size_t)f0 * w * h;
         const float *mg = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
@@ -835,8 +857,8 @@ static int aux_run(dh_predictor *p, const uint16_t *frames, int n, int w, int h,
     float kinv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, kid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (K) mat3_inv_f32(K, kinv);
     HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * sizeof(uint32_t), s));   // hit counters only
-    if (p->geom.flag_words)
-        HIP_TRY(hipMemsetAsync(p->counters + (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3), 0, (size_t)p->cap_frames * p->geom.flag_words * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(p->counters + (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3), 0,
+                           (size_t)p->cap_frames * ((size_t)p->geom.flag_words + (size_t)p->geom.tiles_x * p->geom.tiles_y) * sizeof(uint32_t), s));   // tile flags, window counts
     HIP_TRY(hipMemsetAsync(p->aux_flags, 0, (size_t)n * std::max(g.npatch, 1), s));
     int rc = enqueue_range(p, frames, 0, n, w, h, K ? K : kid, kinv, nullptr, nullptr, nullptr, p->ws_poses, s, false,
                            p->aux_leaf, p->aux_flags, true);
@@ -955,7 +977,8 @@ extern "C" int dh_get_timing(dh_predictor *p, dh_timing *out) {
     if (!p->ev_valid) return fail(DH_ESTATE, "no profiled batch yet (dh_set_profiling + a batch)");
     HIP_TRY(hipEventSynchronize(p->ev[3]));
     HIP_TRY(hipEventElapsedTime(&out->boxsum_ms, p->ev[0], p->ev[4]));
-    HIP_TRY(hipEventElapsedTime(&out->traverse_ms, p->ev[4], p->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&out->traverse_ms, p->ev[4], p->ev[5]));
+    HIP_TRY(hipEventElapsedTime(&out->emit_ms, p->ev[5], p->ev[1]));
     HIP_TRY(hipEventElapsedTime(&out->vote_ms, p->ev[1], p->ev[2]));
     HIP_TRY(hipEventElapsedTime(&out->cluster_ms, p->ev[2], p->ev[3]));
     HIP_TRY(hipEventElapsedTime(&out->total_ms, p->ev[0], p->ev[3]));

@@ -24,7 +24,8 @@ struct __attribute__((aligned(16))) LeafTpl {
     uint32_t ob;                 // first offset vote
     uint32_t rlo, rhi;           // rotation-bin bounding box (rlo = 0xFFFFFFFF: no rotation votes)
     uint32_t rb, n_rot;          // rotation cells: first index, n_distinct_fine | n_distinct_rough << 16
-    uint32_t pad[3];
+    uint32_t flags;              // LF_* again, next to prob: k_emit gates a window with ONE 16-byte gather per tree
+    double   prob;               // leaf probability (houghforest.rs:75), byte offset 56
 };
 
 // Device view of a forest: the flat arrays of dh_forest_desc plus the per-leaf tables that depend
@@ -99,14 +100,35 @@ struct TraverseArgs {
     int stop_phase;         // profiling knob (env DH_TRAV_STOP): 0 = run everything, k = return after phase k
     float kinv[9];
     DevForest f;
+    // window list (read by k_emit): tile t owns slots [t * px * py, t * px * py + win_count[frame][t])
+    uint32_t *win_count;    // [n_frames][tiles] active windows per tile (zeroed per batch by the host)
+    uint32_t *win_patch;    // [n_frames][win_cap] position of the window in the frame's window grid
+    int32_t  *win_leaf;     // [n_frames][T][win_cap] leaf reached in every tree
+    int       win_cap;      // tiles * px * py
+    int32_t  *dbg_leaf;     // nullable [n][npatch][T]
+    uint8_t  *dbg_flags;    // nullable [n][npatch]
+};
+
+// k_emit: probability gate + hit records for every slot of the window list.
+struct EmitArgs {
+    const uint16_t *frames;
+    int n_frames, w, h;
+    int step, lw, lh;
+    int nx, npatch;
+    int px, py, tiles;
+    float kinv[9];
+    DevForest f;
+    const uint32_t *win_count;
+    const uint32_t *win_patch;
+    const int32_t  *win_leaf;
+    int       win_cap;
     HitRec   *hits;
     HitBox   *hit_box;
     HitRot   *hit_rot;
     uint32_t *hit_count;    // [n_frames]
     uint32_t  hits_cap;     // records per frame
     uint32_t *leaf_hits;    // nullable [n_frames][n_leaves]: how often each leaf cast rotation votes (zeroed per batch)
-    int32_t  *dbg_leaf;     // nullable [n][npatch][T]
-    uint8_t  *dbg_flags;    // nullable [n][npatch]
+    uint8_t  *dbg_flags;    // nullable [n][npatch]: bit 1 set for windows that pass the gate
 };
 
 // k_boxsum: per frame the image of all rw x rh rectangle sums, out[y][x] = sum of the rectangle whose
@@ -197,6 +219,7 @@ hipError_t dh_kernels_init();
 hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s);
 hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int swz_q, uint32_t area, void *out, hipStream_t s);
 hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s);
+hipError_t dh_launch_emit(const EmitArgs &a, hipStream_t s);
 hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s);
 hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s);
 hipError_t dh_launch_votes_dump(const VotesDumpArgs &a, hipStream_t s);

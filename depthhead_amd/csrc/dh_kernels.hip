@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) k_leaf_prepare(DevForest f) {
     for (int k = 0; k < 3; ++k) { t.omin[k] = omin[k]; t.omax[k] = omax[k]; }
     t.v = v; t.fc = flags | (n_off << 8); t.ob = ob;
     t.rlo = (flags & LF_ROT) ? f.rbin_box[L] : 0xFFFFFFFFu; t.rhi = f.rbin_box_hi[L];
-    t.rb = rb; t.n_rot = n_fine | (n_rough << 16); t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    t.rb = rb; t.n_rot = n_fine | (n_rough << 16); t.flags = t.fc & 0xffu; t.prob = prob;
     f.tpl[L] = t;
 }
 
@@ -291,7 +291,8 @@ size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_tre
     size_t ss = (size_t)dh_traverse_row_stride(px, step, sw, rw);
     size_t rows = rw > 0 ? fh - rh + 1 : fh + 1;
     size_t npt = (size_t)px * py;
-    return (ss * rows + npt * n_trees + npt * 3 + npt * 2 + 16) * 4;   // keep in step with the carve-up in k_traverse
+    (void)n_trees;
+    return (ss * rows + npt * 2 + 16) * 4;   // keep in step with the carve-up in k_traverse
 }
 
 // n / d for 0 <= n < 2^22 and d >= 1, given rd = 1.0f / d: the float estimate is off by at most one
@@ -574,7 +575,8 @@ __device__ __forceinline__ bool sat_passes(uint32_t *sat, uint32_t *flag, const 
 
 // AL: 8-byte row loads (w % 4 == 0, 8-byte aligned frames: a lane is all inside or all outside the
 // image); RW4: rw % 4 == 0 (the shifted prefix is read back with one 16-byte LDS load).  Both are
-// uniform, and compile-time here so that the loads of a group stay straight-line code.
+// compile-time (the host picks the instance) so that the loads of a group stay straight-line code
+// and every instance gets its own register budget.
 template <bool AL, bool RW4, int RIF>
 __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const uint16_t *img, uint32_t *pex, uint32_t *out,
                                             int lane, int x, int Y0, int y_end, bool store) {
@@ -660,6 +662,7 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
     }
 }
 
+template <bool AL, bool RW4>
 __global__ void __launch_bounds__(BOXW_THREADS) k_boxsum(BoxArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t pex_s[BOXW_WAVES][BOX_SPAN + BOX_MAXR + 8];
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
@@ -675,33 +678,36 @@ __global__ void __launch_bounds__(BOXW_THREADS) k_boxsum(BoxArgs a) {
     const bool store = 4 * lane < a.ow && x + 3 < (a.plane << a.lg);   // columns right of w - rw get clipped-rectangle sums or stay 0
     uint32_t *pex = pex_s[wv];
     uint32_t *out = a.out + (size_t)frame * a.rows * ((size_t)a.plane << a.lg);
-    const bool al = (a.w & 3) == 0 && (((size_t)a.frames) & 7) == 0, rw4 = (a.rw & 3) == 0;
-    if (al && rw4) boxsum_wave<true, true, BOX_ROWS_IN_FLIGHT>(a, frame, img, pex, out, lane, x, Y0, y_end, store);
-    else if (al) boxsum_wave<true, false, BOX_ROWS_IN_FLIGHT>(a, frame, img, pex, out, lane, x, Y0, y_end, store);
-    else if (rw4) boxsum_wave<false, true, 1>(a, frame, img, pex, out, lane, x, Y0, y_end, store);
-    else boxsum_wave<false, false, 1>(a, frame, img, pex, out, lane, x, Y0, y_end, store);
+    boxsum_wave<AL, RW4, AL ? BOX_ROWS_IN_FLIGHT : 1>(a, frame, img, pex, out, lane, x, Y0, y_end, store);
 }
 
 hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s) {
     const int fb = (a.n_frames + 7) / 8;
     if (fb == 0 || a.blocks_per_frame == 0) return hipSuccess;
     if (a.blocks_per_frame > 65535 || fb > 65535) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(k_boxsum, dim3(8, a.blocks_per_frame, fb), dim3(BOXW_THREADS), 0, s, a);
+    // 8-byte row loads need w % 4 == 0 and 8-byte aligned frames; rw % 4 == 0 gives a 16-byte LDS read-back
+    const bool al = (a.w & 3) == 0 && (((size_t)a.frames) & 7) == 0, rw4 = (a.rw & 3) == 0;
+    const dim3 grid(8, a.blocks_per_frame, fb), block(BOXW_THREADS);
+    if (al && rw4) hipLaunchKernelGGL((k_boxsum<true, true>), grid, block, 0, s, a);
+    else if (al) hipLaunchKernelGGL((k_boxsum<true, false>), grid, block, 0, s, a);
+    else if (rw4) hipLaunchKernelGGL((k_boxsum<false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_boxsum<false, false>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
 // Root-to-leaf walks of the uniform path: work item k = (tree k / n_active, active slot k % n_active);
-// a lane takes items tid, tid + 1024, ... W at a time.  HoughTreeFunctions::binarize
+// a lane takes items tid, tid + 1024, ... W at a time.  Leaf ids go to the tile's segment of the frame's
+// window list (wleaf, read by k_emit) and, when the taps are on, to the dense [position][tree] array.  HoughTreeFunctions::binarize
 // (houghforest.rs:185-193) on two rectangle sums with the integer test of NodeU, falling back to
 // the reference's own f64 arithmetic inside the band the integer test cannot decide.
 template <int W>
-__device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32_t *sat, int32_t *leaf, const uint32_t *active,
-                                             int n_active, int total, int cx, int ss, int T) {
+__device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32_t *sat, int32_t *wleaf, int32_t *dleaf, const uint32_t *active,
+                                             const uint32_t *agp, int n_active, int total, int cx, int ss, int T) {
     const int tid = threadIdx.x;
     const NodeU *nodes_u = (const NodeU *)a.nodes_u;
     const float r_active = 1.0f / (float)n_active, r_cx = 1.0f / (float)cx;
     for (int k0 = tid; k0 < total; k0 += W * TRAV_THREADS) {
-        int cur[W], dst[W];
+        int cur[W], dst[W], ddst[W];
         const uint32_t *sp[W];
 #pragma unroll
         for (int i = 0; i < W; ++i) {
@@ -712,7 +718,8 @@ __device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32
             const int p = (int)active[slot];
             const int py = div_small(p, cx, r_cx), px = p - py * cx;
             sp[i] = sat + py * a.step * ss + ((px * a.step) >> a.swz_log2);   // window origins are multiples of m
-            dst[i] = p * T + t;
+            dst[i] = t * a.win_cap + slot;                  // window list: [tree][slot], consecutive lanes -> consecutive words
+            ddst[i] = dleaf ? (int)agp[slot] * T + t : 0;   // dense tap: [window position][tree]
             cur[i] = has ? a.f.roots[t] : -1;
         }
         for (;;) {
@@ -740,7 +747,10 @@ __device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32
         }
 #pragma unroll
         for (int i = 0; i < W; ++i)
-            if (k0 + i * TRAV_THREADS < total) leaf[dst[i]] = ~cur[i];
+            if (k0 + i * TRAV_THREADS < total) {
+                wleaf[dst[i]] = ~cur[i];
+                if (dleaf) dleaf[ddst[i]] = ~cur[i];
+            }
     }
 }
 
@@ -773,25 +783,19 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     const int ss = a.ss_row;
 
     uint32_t *sat = lds;
-    int32_t *leaf = (int32_t *)(sat + a.ss_max);
-    float *p3s = (float *)(leaf + a.px * a.py * T);
-    uint32_t *active = (uint32_t *)(p3s + a.px * a.py * 3);
-    uint32_t *pres = active + a.px * a.py;   // per active slot: hit base | gated << 31
-    uint32_t *misc = pres + a.px * a.py;     // [0] n_active, [1] queue head, [2] hit total, [3] hit base, [4] any pixel
+    uint32_t *active = sat + a.ss_max;         // [px * py] window (inside the tile) of every active slot
+    uint32_t *agp = active + a.px * a.py;      // [px * py] its position in the frame's window grid
+    uint32_t *misc = agp + a.px * a.py;        // [0] n_active, [4] any pixel
 
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
     unsigned long long t_prev = a.dbg_stamps ? clock64() : 0ull;
-    // depth at the centre of this thread's window (phase 2), requested at the start of phase 1 so
-    // that its latency hides behind it
-    uint16_t zc = 0;
 
     // ---- phase 1.  General path: summed-area table of the footprint, modulo 2^32 (footprints of up
     // to 128 x 128 and 256 x 64 pixels are scanned in registers with DPP wave scans, anything else
     // takes the pass-based build).  Uniform path: copy the tile's region of the frame's box-sum image
     // (k_boxsum): cell (y, x) = sum of the rw x rh rectangle whose top-left pixel is (fx0 + x, fy0 + y).
-    // this thread's window (one per thread: npt <= 1024) and the depth at its centre
+    // this thread's window (one per thread: npt <= 1024)
     const int wy = div_small(tid, cx, r_cx), wx = tid - wy * cx;
-    if (tid < npt) zc = img[(size_t)(fy0 + wy * a.step + a.lh) * a.w + fx0 + wx * a.step + a.lw];
     bool nonzero = true;
     if (UNI) {
         // k_boxsum flagged the tiles whose region holds a non-zero rectangle sum; any other tile has only
@@ -857,9 +861,11 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     if (a.stop_phase == 2) return;
     STAMP(2)
 
-    // ---- phase 2: per patch: centre -> 3-D (prediction.rs:551-554), background gate (:567-571)
+    // ---- phase 2: background gate (prediction.rs:567-571).  Active windows are appended to the tile's
+    // segment of the frame's window list (a fixed px * py slots per tile, so no global counter is needed).
+    const size_t wbase = (size_t)tile * (a.px * a.py);   // slot of this tile's first window
+    uint32_t *wpatch = a.win_patch + (size_t)frame * a.win_cap + wbase;
     if (tid < npt) {                                                   // npt <= 1024: one window per thread
-        const int p = tid;
         const int pxi = wx, pyi = wy;
         int ox = pxi * a.step, oy = pyi * a.step;                      // patch origin inside the footprint
         uint32_t sum;
@@ -878,15 +884,20 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         } else {
             sum = sat[(oy + a.sh) * ss + ox + a.sw] - sat[oy * ss + ox + a.sw] - sat[(oy + a.sh) * ss + ox] + sat[oy * ss + ox];
         }
-        int gx = fx0 + ox + a.lw, gy = fy0 + oy + a.lh;                // window centre (x, y)
-        float z = (float)zc;
-        float q[3];
-        to3d(a.kinv, (float)gx, (float)gy, z, q);
-        p3s[p * 3 + 0] = q[0]; p3s[p * 3 + 1] = q[1]; p3s[p * 3 + 2] = q[2];
-        bool nonbg = sum != 0;   // (sum as f64)/(count as f64) > 0.0  <=>  sum > 0
-        if (nonbg) active[atomicAdd(&misc[0], 1u)] = (uint32_t)p;
+        const bool nonbg = sum != 0;   // (sum as f64)/(count as f64) > 0.0  <=>  sum > 0
+        const int gp = (ty * a.py + pyi) * a.nx + tx * a.px + pxi;     // position in the frame's window grid
+        // slot = running count of active windows: one LDS atomic per wave, ranks from the ballot
+        const unsigned long long bal = __ballot(nonbg);
+        uint32_t wave_base = 0;
+        if (lane == 0 && bal) wave_base = atomicAdd(&misc[0], (uint32_t)__popcll(bal));
+        wave_base = __shfl(wave_base, 0);
+        if (nonbg) {
+            const uint32_t slot = wave_base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            active[slot] = (uint32_t)tid;
+            agp[slot] = (uint32_t)gp;
+            wpatch[slot] = (uint32_t)gp;
+        }
         if (a.dbg_flags) {
-            int gp = (ty * a.py + pyi) * a.nx + tx * a.px + pxi;
             a.dbg_flags[(size_t)frame * a.nx * a.ny + gp] = nonbg ? 1 : 0;
             if (!nonbg && a.dbg_leaf)
                 for (int t = 0; t < T; ++t) a.dbg_leaf[((size_t)frame * a.nx * a.ny + gp) * T + t] = -1;
@@ -896,7 +907,8 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     if (a.stop_phase == 3) return;
     STAMP(3)
     const int n_active = (int)misc[0];
-    if (n_active == 0) return;     // nothing to walk, no hits (debug taps were written above)
+    if (tid == 0) a.win_count[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] = (uint32_t)n_active;   // zero for skipped tiles (host memset)
+    if (n_active == 0) return;     // nothing to walk (debug taps were written above)
 
     STAMP(4)
     // ---- phase 3: root->leaf walks.  Work item k = (tree k / n_active, active slot k % n_active),
@@ -908,15 +920,17 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // of the top tree levels and a persistent launch with per-XCD tile queues gain nothing.)
     // Trees are validated acyclic on the host, so every walk ends.
     const int total = n_active * T;
+    int32_t *wleaf = a.win_leaf + (size_t)frame * a.win_cap * T + wbase;                     // [tree][win_cap] per frame
+    int32_t *dleaf = a.dbg_leaf ? a.dbg_leaf + (size_t)frame * a.nx * a.ny * T : nullptr;
     if (UNI) {
         // W walks per lane, advanced in lock step: their node fetches and box-sum reads are
         // independent, so each lane keeps W dependent-load chains in flight.  W = walks per lane
         // of this tile (at most 4), so one pass covers the tile whenever it has <= 4096 walks.
         const int per_lane = (total + TRAV_THREADS - 1) / TRAV_THREADS;
-        if (per_lane <= 1) walk_uniform<1>(a, sat, leaf, active, n_active, total, cx, ss, T);
-        else if (per_lane == 2) walk_uniform<2>(a, sat, leaf, active, n_active, total, cx, ss, T);
-        else if (per_lane == 3) walk_uniform<3>(a, sat, leaf, active, n_active, total, cx, ss, T);
-        else walk_uniform<4>(a, sat, leaf, active, n_active, total, cx, ss, T);
+        if (per_lane <= 1) walk_uniform<1>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+        else if (per_lane == 2) walk_uniform<2>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+        else if (per_lane == 3) walk_uniform<3>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+        else walk_uniform<4>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
     } else {
         for (int k = tid; k < total; k += TRAV_THREADS) {
             const int t = div_small(k, n_active, 1.0f / (float)n_active), slot = k - t * n_active;
@@ -938,135 +952,175 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
                 const double a2 = c2 ? __ddiv_rn((double)s2, (double)c2) : 0.0;
                 cur = (__dsub_rn(a1, a2) > thr) ? (int)n1.w : (int)n1.z;
             }
-            leaf[p * T + t] = ~cur;
+            wleaf[(size_t)t * a.win_cap + slot] = ~cur;
+            if (dleaf) dleaf[(size_t)agp[slot] * T + t] = ~cur;
         }
     }
-    __syncthreads();
 
-    if (a.stop_phase == 4) return;
     STAMP(5)
-    // ---- phase 4: mean leaf probability in tree order (prediction.rs:582-584), hit records.
-    // The SAT / box image is dead now; its LDS is reused as scratch for the (patch, tree) pairs so
-    // that every dependent global load of this phase is issued by a different thread.
-    const int pairs = n_active * T;
-    const float r_T = 1.0f / (float)T;
-    double *sprob = (double *)sat;                       // [pairs]
-    uint32_t *sflag = (uint32_t *)(sprob + pairs);       // [pairs]
-    const bool fits = (size_t)pairs * 12 <= (size_t)a.ss_max * 4;
-    if (fits) {
-        for (int i = tid; i < pairs; i += TRAV_THREADS) {
-            const int slot = div_small(i, T, r_T), t = i - slot * T;
-            const uint32_t lid = (uint32_t)leaf[(int)active[slot] * T + t];
-            sprob[i] = a.f.leaf_prob[lid];
-            sflag[i] = a.f.leaf_flags[lid];
-        }
-        __syncthreads();
-        if (tid < n_active) {
-            double prob = 0.0;
-            for (int t = 0; t < T; ++t) prob = __dadd_rn(prob, sprob[tid * T + t]);     // tree order, f64
-            prob = __ddiv_rn(prob, (double)T);
-            const bool gated = prob > DH_PROB_GATE;
-            uint32_t cnt = 0;
-            if (gated)
-                for (int t = 0; t < T; ++t) {
-                    const uint32_t lf = sflag[tid * T + t];
-                    if ((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF))) cnt++;
-                }
-            pres[tid] = (cnt ? atomicAdd(&misc[2], cnt) : 0u) | (gated ? 0x80000000u : 0u);
-            if (a.dbg_flags) {
-                const int p = (int)active[tid], pxi = p % cx, pyi = p / cx;
-                const int gp = (ty * a.py + pyi) * a.nx + tx * a.px + pxi;
-                const size_t o = (size_t)frame * a.nx * a.ny + gp;
-                if (gated) a.dbg_flags[o] = 3;
-                if (a.dbg_leaf)
-                    for (int t = 0; t < T; ++t) a.dbg_leaf[o * T + t] = leaf[p * T + t];
-            }
-        }
-        __syncthreads();
-        if (misc[2] == 0) return;
-        if (tid == 0) misc[3] = atomicAdd(&a.hit_count[frame], misc[2]);
-        __syncthreads();
-        HitRec *dst = a.hits + (size_t)frame * a.hits_cap;
-        HitBox *dbox = a.hit_box + (size_t)frame * a.hits_cap;
-        HitRot *drot = a.hit_rot + (size_t)frame * a.hits_cap;
-        for (int i = tid; i < pairs; i += TRAV_THREADS) {
-            const int slot = div_small(i, T, r_T), t = i - slot * T;
-            const uint32_t pr = pres[slot], lf = sflag[i];
-            if (!(pr & 0x80000000u) || !((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF)))) continue;
-            uint32_t o = misc[3] + (pr & 0x7fffffffu);
-            for (int t2 = 0; t2 < t; ++t2) {                 // rank among this patch's voting leaves
-                const uint32_t l2 = sflag[slot * T + t2];
-                o += ((l2 & LF_PROB) && (l2 & (LF_ROT | LF_OFF))) ? 1u : 0u;
-            }
-            if (o >= a.hits_cap) continue;
-            const int p = (int)active[slot];
-            const uint32_t lid = (uint32_t)leaf[p * T + t];
-            const uint4 *tp = (const uint4 *)(a.f.tpl + lid);
-            const uint4 t0 = tp[0], t1 = tp[1], t2v = tp[2], t3 = tp[3];
-            const float q0 = p3s[p * 3 + 0], q1 = p3s[p * 3 + 1], q2 = p3s[p * 3 + 2];
-            const float mn0 = __uint_as_float(t0.x), mn1 = __uint_as_float(t0.y), mn2 = __uint_as_float(t0.z),
-                        mx0 = __uint_as_float(t0.w), mx1 = __uint_as_float(t1.x), mx2 = __uint_as_float(t1.y);
-            *(float4 *)(dst + o) = make_float4(q0, q1, q2, __uint_as_float(t2v.x));              // p3, ob
-            ((int4 *)(dbox + o))[0] = make_int4(f32_as_i32(__fsub_rn(q0, mx0)), f32_as_i32(__fsub_rn(q1, mx1)),
-                                                 f32_as_i32(__fsub_rn(q2, mx2)), f32_as_i32(__fsub_rn(q0, mn0)));
-            ((int4 *)(dbox + o))[1] = make_int4(f32_as_i32(__fsub_rn(q1, mn1)), f32_as_i32(__fsub_rn(q2, mn2)), (int)t1.z, (int)t1.w);
-            *(uint4 *)(drot + o) = make_uint4(t2v.y, t2v.z, t2v.w, t3.x);                           // rlo, rhi, rb, n_rot
-            if (a.leaf_hits && (lf & LF_ROT)) atomicAdd(&a.leaf_hits[(size_t)frame * a.f.n_leaves + lid], 1u);
-        }
-        STAMP(6)
-        return;
+}
+
+// ================================================================== k_emit
+// One thread per active window of the list k_traverse wrote: mean leaf probability in tree order
+// (prediction.rs:582-584), the > 0.7 gate, and one self-contained hit record per voting leaf
+// (consumed by k_vote and k_cluster).  No LDS, no barriers: the three dependent global round trips
+// (leaf probabilities, the frame's hit counter, the leaf templates) that used to end every
+// k_traverse workgroup are hidden here by plain occupancy.
+#define EMIT_THREADS 256
+#define EMIT_BATCH 16
+__global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
+    const int frame = blockIdx.y, lane = threadIdx.x & (WAVE - 1);
+    const int pp = a.px * a.py;
+    // Thread i of the frame takes the i-th active window in tile order: every wave scans the tiles'
+    // counts itself (64 tiles per step, one load per lane) and finds its tile with a binary search
+    // over the running totals, so only the blocks past the frame's last active window are idle.
+    const uint32_t *counts = a.win_count + (size_t)frame * a.tiles;
+    const uint32_t idx = (uint32_t)blockIdx.x * EMIT_THREADS + threadIdx.x;
+    uint32_t before = 0;                 // active windows in the tiles of earlier steps
+    int tile = -1, slot = 0;
+    for (int t0 = 0; t0 < a.tiles; t0 += WAVE) {
+        const uint32_t c = t0 + lane < a.tiles ? counts[t0 + lane] : 0u;
+        const uint32_t inc = wave_incl_scan(c);
+        const uint32_t step_total = (uint32_t)__shfl((int)inc, WAVE - 1);
+        // (all lanes run the search: a shuffle must not read a lane that sits out a divergent branch)
+        const uint32_t r = idx - before;                                  // rank inside this step, if the window is in it
+        int s = 0;                                                        // = number of lanes whose running total is <= r
+#pragma unroll
+        for (int b = WAVE / 2; b; b >>= 1)
+            if ((uint32_t)__shfl((int)inc, s + b - 1) <= r) s += b;
+        s = min(s, WAVE - 1);
+        const uint32_t first = (uint32_t)__shfl((int)inc, s) - (uint32_t)__shfl((int)c, s);
+        if (tile < 0 && idx >= before && r < step_total) { tile = t0 + s; slot = (int)(r - first); }
+        before += step_total;
+        if (__ballot(tile < 0) == 0ull) break;
     }
-    // ---- fallback for forests too large for the scratch (n_active * T * 12 bytes > SAT): one thread per patch
-    uint32_t my_hits = 0, my_base = 0;
-    int my_p = -1;
+    const bool live = tile >= 0;
+    if (__ballot(live) == 0ull) return;
+    if (!live) { tile = 0; slot = 0; }
+    const int T = (int)a.f.n_trees;
+    const size_t w = (size_t)tile * pp + slot;                           // slot in the frame's window list
+    uint32_t cnt = 0, gp = 0;
     bool gated = false;
-    if (tid < n_active) {
-        my_p = (int)active[tid];
+    const int32_t *wl = a.win_leaf + (size_t)frame * a.win_cap * T + w;
+    unsigned long long voting = 0;          // bit t: the leaf reached in tree t casts votes (T <= 64; else recomputed below)
+    uint16_t zc = 0;                        // depth at the window centre
+    if (live) {
+        gp = a.win_patch[(size_t)frame * a.win_cap + w];
+        // Batches of EMIT_BATCH trees: the leaf ids, then their probabilities and flags, are requested
+        // together, so a window costs two dependent round trips per batch (one batch for T <= 16).
         double prob = 0.0;
-        for (int t = 0; t < T; ++t) prob = __dadd_rn(prob, a.f.leaf_prob[leaf[my_p * T + t]]);
+        for (int t0 = 0; t0 < T; t0 += EMIT_BATCH) {
+            uint32_t l[EMIT_BATCH], lf[EMIT_BATCH];
+            double pr[EMIT_BATCH];
+            uint4 g[EMIT_BATCH];
+#pragma unroll
+            for (int k = 0; k < EMIT_BATCH; ++k) l[k] = (uint32_t)wl[(size_t)min(t0 + k, T - 1) * a.win_cap];
+            if (t0 == 0) {
+                // window centre (for prediction.rs:551-554), requested now: its latency hides behind the batch
+                const int gyi = (int)(gp / (uint32_t)a.nx), gxi = (int)gp - gyi * a.nx;
+                zc = a.frames[(size_t)frame * a.w * a.h + (size_t)(gyi * a.step + a.lh) * a.w + gxi * a.step + a.lw];
+            }
+#pragma unroll
+            for (int k = 0; k < EMIT_BATCH; ++k) g[k] = ((const uint4 *)(a.f.tpl + l[k]))[3];             // n_rot, flags, prob
+#pragma unroll
+            for (int k = 0; k < EMIT_BATCH; ++k) { lf[k] = g[k].y; pr[k] = __hiloint2double((int)g[k].w, (int)g[k].z); }
+#pragma unroll
+            for (int k = 0; k < EMIT_BATCH; ++k)
+                if (t0 + k < T) {
+                    prob = __dadd_rn(prob, pr[k]);                                   // tree order, f64 (prediction.rs:582-584)
+                    if ((lf[k] & LF_PROB) && (lf[k] & (LF_ROT | LF_OFF))) { cnt++; voting |= 1ull << ((t0 + k) & 63); }
+                }
+        }
         prob = __ddiv_rn(prob, (double)T);
         gated = prob > DH_PROB_GATE;
-        if (gated)
-            for (int t = 0; t < T; ++t) {
-                uint32_t lf = a.f.leaf_flags[leaf[my_p * T + t]];
-                if ((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF))) my_hits++;
-            }
-        if (my_hits) my_base = atomicAdd(&misc[2], my_hits);
-        if (a.dbg_flags) {
-            int pxi = my_p % cx, pyi = my_p / cx;
-            int gp = (ty * a.py + pyi) * a.nx + tx * a.px + pxi;
-            size_t o = (size_t)frame * a.nx * a.ny + gp;
-            if (gated) a.dbg_flags[o] = 3;
-            if (a.dbg_leaf)
-                for (int t = 0; t < T; ++t) a.dbg_leaf[o * T + t] = leaf[my_p * T + t];
-        }
+        if (!gated) { cnt = 0; voting = 0; }
+        if (gated && a.dbg_flags) a.dbg_flags[(size_t)frame * a.npatch + gp] = 3;
     }
-    __syncthreads();
-    if (misc[2] == 0) return;
-    if (tid == 0) misc[3] = atomicAdd(&a.hit_count[frame], misc[2]);
-    __syncthreads();
-    if (my_hits) {
-        uint32_t o = misc[3] + my_base;
-        HitRec *dst = a.hits + (size_t)frame * a.hits_cap;
-        HitBox *dbox = a.hit_box + (size_t)frame * a.hits_cap;
-        HitRot *drot = a.hit_rot + (size_t)frame * a.hits_cap;
-        float q0 = p3s[my_p * 3 + 0], q1 = p3s[my_p * 3 + 1], q2 = p3s[my_p * 3 + 2];
-        for (int t = 0; t < T; ++t) {
-            uint32_t lid = (uint32_t)leaf[my_p * T + t];
-            const LeafTpl tp = a.f.tpl[lid];
-            if ((tp.fc & LF_PROB) && (tp.fc & (LF_ROT | LF_OFF))) {
-                if (o < a.hits_cap) {
-                    *(float4 *)(dst + o) = make_float4(q0, q1, q2, __uint_as_float(tp.ob));
-                    ((int4 *)(dbox + o))[0] = make_int4(f32_as_i32(__fsub_rn(q0, tp.omax[0])), f32_as_i32(__fsub_rn(q1, tp.omax[1])),
-                                                         f32_as_i32(__fsub_rn(q2, tp.omax[2])), f32_as_i32(__fsub_rn(q0, tp.omin[0])));
-                    ((int4 *)(dbox + o))[1] = make_int4(f32_as_i32(__fsub_rn(q1, tp.omin[1])), f32_as_i32(__fsub_rn(q2, tp.omin[2])), (int)tp.v, (int)tp.fc);
-                    *(uint4 *)(drot + o) = make_uint4(tp.rlo, tp.rhi, tp.rb, tp.n_rot);
-                    if (a.leaf_hits && (tp.fc & LF_ROT)) atomicAdd(&a.leaf_hits[(size_t)frame * a.f.n_leaves + lid], 1u);
+    // slots in the frame's hit arrays: one atomic per wave, exclusive prefix of the lanes' counts
+    const uint32_t incl = wave_incl_scan(cnt);
+    const uint32_t wave_total = __shfl(incl, WAVE - 1);
+    if (wave_total == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&a.hit_count[frame], wave_total);
+    base = __shfl(base, 0);
+    const uint32_t excl = incl - cnt;
+    // window centre -> 3-D (prediction.rs:551-554), by the lanes whose window votes
+    float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+    if (cnt) {
+        const int gyi = (int)(gp / (uint32_t)a.nx), gxi = (int)gp - gyi * a.nx;
+        float q[3];
+        to3d(a.kinv, (float)(gxi * a.step + a.lw), (float)(gyi * a.step + a.lh), (float)zc, q);
+        q0 = q[0]; q1 = q[1]; q2 = q[2];
+    }
+    HitRec *dst = a.hits + (size_t)frame * a.hits_cap;
+    HitBox *dbox = a.hit_box + (size_t)frame * a.hits_cap;
+    HitRot *drot = a.hit_rot + (size_t)frame * a.hits_cap;
+    const int32_t *wlf = a.win_leaf + (size_t)frame * a.win_cap * T;
+    const int wi = (int)w;
+    // One LANE per hit record: hit h of the wave belongs to the voting window (lane) s with
+    // excl_s <= h < excl_s + cnt_s and is its (h - excl_s)-th voting tree.  Every lane finds its (s, tree)
+    // with two six-step binary searches (over the prefix counts, then over the voting mask), and all
+    // records of the wave are built at once: one leaf-id load, one template load, one store per lane
+    // instead of a per-window loop over the trees.
+    for (uint32_t chunk = 0; chunk < wave_total; chunk += WAVE) {
+        int src = 0, tree = 0;
+        if (T <= 64) {
+            // src = number of lanes whose inclusive count is <= h (the counts are non-decreasing)
+            const uint32_t h = chunk + (uint32_t)lane;
+#pragma unroll
+            for (int b = WAVE / 2; b; b >>= 1)
+                if ((uint32_t)__shfl((int)incl, src + b - 1) <= h) src += b;
+            src = min(src, WAVE - 1);                                     // lanes past the last hit: any valid source
+            uint32_t n = h - (uint32_t)__shfl((int)excl, src);            // rank of the hit among its window's voting trees
+            const uint32_t vlo = (uint32_t)__shfl((int)(uint32_t)voting, src), vhi = (uint32_t)__shfl((int)(uint32_t)(voting >> 32), src);
+            // tree = position of the n-th set bit of the window's voting mask
+            uint32_t word = vlo;
+            const uint32_t clo = (uint32_t)__popc(vlo);
+            if (n >= clo) { n -= clo; word = vhi; tree = 32; }
+#pragma unroll
+            for (int b = 16; b; b >>= 1) {
+                const uint32_t c = (uint32_t)__popc(word & ((1u << b) - 1u));
+                if (n >= c) { n -= c; word >>= b; tree += b; }
+            }
+        } else {
+            // more than 64 trees: every lane finds its hit by walking the voting lanes' leaves itself
+            const uint32_t h = chunk + (uint32_t)lane;
+            for (int sl = 0; sl < WAVE; ++sl) {
+                const uint32_t ex = (uint32_t)__shfl((int)excl, sl), cn = (uint32_t)__shfl((int)cnt, sl);
+                const int sw = __shfl(wi, sl);
+                if (h < ex || h >= ex + cn) continue;
+                uint32_t r = ex;
+                for (int t = 0; t < T; ++t) {
+                    const uint32_t lf = a.f.leaf_flags[(uint32_t)wlf[(size_t)t * a.win_cap + sw]];
+                    if ((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF))) { if (r == h) { src = sl; tree = t; } ++r; }
                 }
-                o++;
             }
         }
+        const uint32_t h = chunk + (uint32_t)lane;
+        const int sw = __shfl(wi, src);
+        const float p0 = __shfl(q0, src), p1 = __shfl(q1, src), p2 = __shfl(q2, src);
+        const uint32_t o = base + h;
+        if (h < wave_total && o < a.hits_cap) {
+            const uint32_t lid = (uint32_t)wlf[(size_t)tree * a.win_cap + sw];
+            const uint4 *tp = (const uint4 *)(a.f.tpl + lid);
+            const uint4 t0 = tp[0], t1 = tp[1], t2v = tp[2], t3 = tp[3];
+            const float mn0 = __uint_as_float(t0.x), mn1 = __uint_as_float(t0.y), mn2 = __uint_as_float(t0.z),
+                        mx0 = __uint_as_float(t0.w), mx1 = __uint_as_float(t1.x), mx2 = __uint_as_float(t1.y);
+            *(float4 *)(dst + o) = make_float4(p0, p1, p2, __uint_as_float(t2v.x));              // p3, ob
+            ((int4 *)(dbox + o))[0] = make_int4(f32_as_i32(__fsub_rn(p0, mx0)), f32_as_i32(__fsub_rn(p1, mx1)),
+                                                 f32_as_i32(__fsub_rn(p2, mx2)), f32_as_i32(__fsub_rn(p0, mn0)));
+            ((int4 *)(dbox + o))[1] = make_int4(f32_as_i32(__fsub_rn(p1, mn1)), f32_as_i32(__fsub_rn(p2, mn2)), (int)t1.z, (int)t1.w);
+            *(uint4 *)(drot + o) = make_uint4(t2v.y, t2v.z, t2v.w, t3.x);                           // rlo, rhi, rb, n_rot
+            if (a.leaf_hits && (t1.w & LF_ROT)) atomicAdd(&a.leaf_hits[(size_t)frame * a.f.n_leaves + lid], 1u);
+        }
     }
+}
+
+hipError_t dh_launch_emit(const EmitArgs &a, hipStream_t s) {
+    if (a.n_frames == 0 || a.tiles == 0 || a.npatch == 0) return hipSuccess;
+    if (a.n_frames > 65535) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_emit, dim3((a.npatch + EMIT_THREADS - 1) / EMIT_THREADS, a.n_frames), dim3(EMIT_THREADS), 0, s, a);
+    return hipGetLastError();
 }
 
 // Raise the dynamic-LDS limit of the walk kernel (once per process; not allowed during stream capture,

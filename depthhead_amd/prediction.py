@@ -208,7 +208,7 @@ class HoughPrediction:
     def timing(self) -> dict:
         t = _lib.Timing()
         check(self._lib.dh_get_timing(self._ph, C.byref(t)))
-        return {"boxsum_ms": t.boxsum_ms, "traverse_ms": t.traverse_ms, "vote_ms": t.vote_ms,
+        return {"boxsum_ms": t.boxsum_ms, "traverse_ms": t.traverse_ms, "emit_ms": t.emit_ms, "vote_ms": t.vote_ms,
                 "cluster_ms": t.cluster_ms, "total_ms": t.total_ms, "n_frames": t.n_frames}
 
     # ---- parity taps (tests) -------------------------------------------------------------

@@ -101,12 +101,14 @@ typedef struct dh_predictor dh_predictor; /* opaque, one per thread/stream */
 
 /* Average duration of each kernel over the last batch, when profiling is on. */
 typedef struct dh_timing {
-    float traverse_ms; /* tile build + tree walks + gates + hit records (excludes boxsum_ms) */
+    float traverse_ms; /* tile build + background gate + tree walks (excludes boxsum_ms, emit_ms) */
     float vote_ms;     /* coarse 20x20 / 20^3 guess grids                    */
     float cluster_ms;  /* initial guesses + both mean shifts                 */
     float total_ms;    /* first kernel start -> last kernel end              */
     uint32_t n_frames;
     float boxsum_ms;   /* rectangle-sum images (uniform-rectangle forests only, else 0) */
+    float emit_ms;     /* probability gate + hit records                     */
+    uint32_t reserved;
 } dh_timing;
 
 const char *dh_last_error(void);

@@ -32,7 +32,7 @@ def test_exports_every_declared_symbol(hip_lib):
 def test_pod_layouts_match_header():
     assert NODE_DTYPE.itemsize == 32 and NODE_DTYPE.fields["threshold"][1] == 16 and NODE_DTYPE.fields["child_one"][1] == 28
     assert _lib.POSE_DTYPE.itemsize == 40 and _lib.POSE_DTYPE.fields["rotation"][1] == 16
-    assert C.sizeof(_lib.Params) == 20 and C.sizeof(_lib.Timing) == 24
+    assert C.sizeof(_lib.Params) == 20 and C.sizeof(_lib.Timing) == 32
     assert C.sizeof(_lib.ForestDesc) == 80
 
 
