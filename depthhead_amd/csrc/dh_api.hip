@@ -609,7 +609,17 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ba.tbh = (g.py - 1) * (int)p->params.stepwidth + (int)p->params.subimage_height - p->f_rh + 1;
         ba.out = box; ba.plane = g.box_plane; ba.rows = g.box_rows; ba.lg = g.swz_log2;
         ba.ow = g.box_ow; ba.oh = g.box_oh; ba.parts = g.box_parts; ba.bands = g.box_bands;
-        ba.blocks_per_frame = (g.box_parts * g.box_bands + 3) / 4;
+        // LDS-ring instance (each pixel read once): 4 waves x (rh - 1) packed rows per workgroup, so about
+        // 12 waves fit a CU; the bands are made as tall as keeps the whole launch resident at once
+        static const bool ring_on = !getenv("DH_BOX_NO_RING");
+        if (ring_on && p->f_rh >= 2 && p->f_rh - 1 <= 28) {      // 4 x 28 x 512 B + the prefix rows < 64 KB
+            const long waves_max = 12L * 256;
+            int bands = (int)std::max(1L, std::min<long>(std::max(1, g.box_rows / 16), waves_max / std::max(1L, (long)n * g.box_parts)));
+            ba.oh = (g.box_rows + bands - 1) / bands;
+            ba.bands = (g.box_rows + ba.oh - 1) / ba.oh;
+            ba.ring = 1;
+        }
+        ba.blocks_per_frame = (ba.parts * ba.bands + 3) / 4;
         HIP_TRY(dh_launch_boxsum(ba, s));
     }
     if (profile) HIP_TRY(hipEventRecord(p->ev[4], s));

@@ -146,6 +146,7 @@ struct BoxArgs {
     int tpx, tpy, tbw, tbh;
     int parts, bands;       // waves across / down a frame
     int blocks_per_frame;   // ceil(parts * bands / 4)
+    int ring;               // 1: keep the rh - 1 window rows in a wave-private LDS ring (rh - 1 <= 28) instead of re-reading them
 };
 
 struct VoteArgs {

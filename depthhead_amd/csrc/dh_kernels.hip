@@ -577,8 +577,8 @@ __device__ __forceinline__ bool sat_passes(uint32_t *sat, uint32_t *flag, const 
 // image); RW4: rw % 4 == 0 (the shifted prefix is read back with one 16-byte LDS load).  Both are
 // compile-time (the host picks the instance) so that the loads of a group stay straight-line code
 // and every instance gets its own register budget.
-template <bool AL, bool RW4, int RIF>
-__device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const uint16_t *img, uint32_t *pex, uint32_t *out,
+template <bool AL, bool RW4, int RIF, bool RING>
+__device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const uint16_t *img, uint32_t *pex, uint2 *ring, uint32_t *out,
                                             int lane, int x, int Y0, int y_end, bool store) {
     // Columns right of the image read a.zeros with row stride 0 instead of being masked, so every
     // load is unconditional and nothing has to wait for it before its use.
@@ -592,9 +592,12 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
                           (uint32_t)c2[(size_t)y * s2] | ((uint32_t)c3[(size_t)y * s3] << 16));
     };
     // Step t brings image row Y0 + t into the rh-row window; from t = rh - 1 on it also emits output
-    // row Y0 + t - (rh - 1) and then drops that row from the window.  Steps run in groups of
-    // RIF (rows in flight; 1 on the 2-byte-load path to stay within 64 VGPRs) whose loads are issued one whole group ahead of their use (during the
-    // warm-up steps the "leaving" loads fetch row Y0 and are ignored).
+    // row Y0 + t - (rh - 1) and then drops that row from the window.  Steps run in groups of RIF
+    // (rows in flight; 1 on the 2-byte-load path to stay within 64 VGPRs) whose loads are issued one
+    // whole group ahead of their use.  The row that leaves the window was loaded rh - 1 steps
+    // earlier: with RING it is kept in a wave-private LDS ring of rh - 1 packed rows (so every pixel
+    // crosses the memory system once); without, it is simply fetched again (during the warm-up steps
+    // those fetches read row Y0 and are ignored).
     const int nsteps = (a.rh - 1) + (y_end - Y0), warm = a.rh - 1;
     const uint32_t *pex_rd = pex + 4 * lane + a.rw;
     // output slots of this lane's four columns within a row: plane (x mod m), position x / m
@@ -606,24 +609,31 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
     uint8_t *flags = a.tile_flags + (size_t)frame * a.tiles_x * a.tiles_y;
     const float r_tpx = 1.0f / (float)a.tpx, r_tpy = 1.0f / (float)a.tpy;
     uint2 e[RIF], l[RIF], en[RIF], ln[RIF];
+    int rs = 0;                          // ring slot of step t: t mod (rh - 1)
 #pragma unroll
     for (int k = 0; k < RIF; ++k) {
         const int t = min(k, nsteps - 1);
         e[k] = load_row(Y0 + t);
-        l[k] = load_row(Y0 + max(t - warm, 0));
+        l[k] = RING ? make_uint2(0u, 0u) : load_row(Y0 + max(t - warm, 0));
     }
     for (int t0 = 0; t0 < nsteps; t0 += RIF) {
 #pragma unroll
         for (int k = 0; k < RIF; ++k) {
             const int t = min(t0 + RIF + k, nsteps - 1);
             en[k] = load_row(Y0 + t);
-            ln[k] = load_row(Y0 + max(t - warm, 0));
+            ln[k] = RING ? make_uint2(0u, 0u) : load_row(Y0 + max(t - warm, 0));
         }
 #pragma unroll
         for (int k = 0; k < RIF; ++k) {
             const int t = t0 + k;
             if (t >= nsteps) break;
             v0 += e[k].x & 0xffffu; v1 += e[k].x >> 16; v2 += e[k].y & 0xffffu; v3 += e[k].y >> 16;
+            if (RING && warm > 0) {
+                // swap the entering row into the slot of the row that leaves at this step
+                if (t >= warm) l[k] = ring[rs * WAVE + lane];
+                ring[rs * WAVE + lane] = e[k];
+                if (++rs == warm) rs = 0;
+            }
             if (t < warm) continue;
             const uint32_t e1 = v0, e2 = v0 + v1, e3 = e2 + v2, tot = e3 + v3;
             const uint32_t base = wave_incl_scan(tot) - tot;               // sum of the columns left of this lane
@@ -662,9 +672,10 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
     }
 }
 
-template <bool AL, bool RW4>
+template <bool AL, bool RW4, bool RING>
 __global__ void __launch_bounds__(BOXW_THREADS) k_boxsum(BoxArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t pex_s[BOXW_WAVES][BOX_SPAN + BOX_MAXR + 8];
+    extern __shared__ __attribute__((aligned(16))) uint32_t box_dyn[];       // RING: [BOXW_WAVES][rh - 1][64] packed rows
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     const int frame = (int)blockIdx.z * 8 + (int)blockIdx.x;     // grid (8, blocks per frame, frames / 8): same frame -> XCD mapping as k_traverse
     const int unit = (int)blockIdx.y * BOXW_WAVES + wv;
@@ -677,21 +688,31 @@ __global__ void __launch_bounds__(BOXW_THREADS) k_boxsum(BoxArgs a) {
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
     const bool store = 4 * lane < a.ow && x + 3 < (a.plane << a.lg);   // columns right of w - rw get clipped-rectangle sums or stay 0
     uint32_t *pex = pex_s[wv];
+    uint2 *ring = (uint2 *)box_dyn + (size_t)wv * (a.rh - 1) * WAVE;
     uint32_t *out = a.out + (size_t)frame * a.rows * ((size_t)a.plane << a.lg);
-    boxsum_wave<AL, RW4, AL ? BOX_ROWS_IN_FLIGHT : 1>(a, frame, img, pex, out, lane, x, Y0, y_end, store);
+    boxsum_wave<AL, RW4, AL ? BOX_ROWS_IN_FLIGHT : 1, RING>(a, frame, img, pex, ring, out, lane, x, Y0, y_end, store);
 }
 
 hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s) {
     const int fb = (a.n_frames + 7) / 8;
     if (fb == 0 || a.blocks_per_frame == 0) return hipSuccess;
     if (a.blocks_per_frame > 65535 || fb > 65535) return hipErrorInvalidConfiguration;
-    // 8-byte row loads need w % 4 == 0 and 8-byte aligned frames; rw % 4 == 0 gives a 16-byte LDS read-back
+    // 8-byte row loads need w % 4 == 0 and 8-byte aligned frames; rw % 4 == 0 gives a 16-byte LDS read-back;
+    // a.ring: the host sized the bands for the LDS-ring instance (rh - 1 packed rows per wave)
     const bool al = (a.w & 3) == 0 && (((size_t)a.frames) & 7) == 0, rw4 = (a.rw & 3) == 0;
     const dim3 grid(8, a.blocks_per_frame, fb), block(BOXW_THREADS);
-    if (al && rw4) hipLaunchKernelGGL((k_boxsum<true, true>), grid, block, 0, s, a);
-    else if (al) hipLaunchKernelGGL((k_boxsum<true, false>), grid, block, 0, s, a);
-    else if (rw4) hipLaunchKernelGGL((k_boxsum<false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_boxsum<false, false>), grid, block, 0, s, a);
+    const size_t ring_bytes = a.ring ? (size_t)BOXW_WAVES * (a.rh - 1) * WAVE * sizeof(uint2) : 0;
+    if (a.ring) {
+        if (al && rw4) hipLaunchKernelGGL((k_boxsum<true, true, true>), grid, block, ring_bytes, s, a);
+        else if (al) hipLaunchKernelGGL((k_boxsum<true, false, true>), grid, block, ring_bytes, s, a);
+        else if (rw4) hipLaunchKernelGGL((k_boxsum<false, true, true>), grid, block, ring_bytes, s, a);
+        else hipLaunchKernelGGL((k_boxsum<false, false, true>), grid, block, ring_bytes, s, a);
+    } else {
+        if (al && rw4) hipLaunchKernelGGL((k_boxsum<true, true, false>), grid, block, 0, s, a);
+        else if (al) hipLaunchKernelGGL((k_boxsum<true, false, false>), grid, block, 0, s, a);
+        else if (rw4) hipLaunchKernelGGL((k_boxsum<false, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_boxsum<false, false, false>), grid, block, 0, s, a);
+    }
     return hipGetLastError();
 }
 
