@@ -611,7 +611,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ba.ow = g.box_ow; ba.oh = g.box_oh; ba.parts = g.box_parts; ba.bands = g.box_bands;
         // LDS-ring instance (each pixel read once): 4 waves x (rh - 1) packed rows per workgroup, so about
         // 12 waves fit a CU; the bands are made as tall as keeps the whole launch resident at once
-        static const bool ring_on = !getenv("DH_BOX_NO_RING");
+        const bool ring_on = !getenv("DH_BOX_NO_RING");
         if (ring_on && p->f_rh >= 2 && p->f_rh - 1 <= 28) {      // 4 x 28 x 512 B + the prefix rows < 64 KB
             const long waves_max = 12L * 256;
             int bands = (int)std::max(1L, std::min<long>(std::max(1, g.box_rows / 16), waves_max / std::max(1L, (long)n * g.box_parts)));

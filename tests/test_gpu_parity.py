@@ -351,13 +351,53 @@ def test_hand_verified_case(hp_mod):
     hc.check(r.mid_point, r.rotation)
 
 
-def test_many_trees_scratch_fallback(hp_mod, oracle):
-    """64 shallow trees: the (patch, tree) scratch of k_traverse's last phase no longer fits the
-    freed SAT, so the per-patch fallback runs."""
-    forest = synth.synth_forest(64, 4, synth.FOREST_SEED_BASE + 160, full_depth=3)
+@pytest.mark.parametrize("trees", [64, 70])
+def test_many_trees(hp_mod, oracle, trees):
+    """64 / 70 shallow trees: several passes of walks per tile; k_emit gathers the leaves in batches of
+    16 trees and, beyond 64 trees (no 64-bit voting mask), deals hit records with its generic search."""
+    forest = synth.synth_forest(trees, 4, synth.FOREST_SEED_BASE + 160, full_depth=3)
     model = synth.ModelParams(stepwidth=4)
     frames = synth.biwi_batch(2, 240, 200, first=70)
     _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(240, 200), full=False)
+
+
+class env_override:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        import os
+        for k, v in self.kv.items():
+            os.environ[k] = str(v)
+
+    def __exit__(self, *exc):
+        import os
+        for k in self.kv:
+            os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("w,h,step,rect_scale,tile", [
+    (642, 300, 4, 0.3, None),     # w % 4 != 0: 2-byte row loads in k_boxsum
+    (640, 300, 4, 0.27, None),    # 21 x 21 rectangles: rw % 4 != 0 (unaligned LDS read-back), LDS ring
+    (640, 300, 4, 0.4, None),     # 32 x 32 rectangles: rh - 1 > 28, no LDS ring
+    (640, 300, 8, 0.3, None),     # stride 8: columns de-interleaved by 8
+    (640, 300, 6, 0.3, None),     # stride 6: by 2
+    (640, 300, 3, 0.3, None),     # odd stride: linear region
+    (640, 300, 4, 0.3, "5,3"),    # forced tile with px % 4 != 0: element-wise region copy instead of direct-to-LDS
+    (640, 300, 4, 0.3, "12,7"),
+])
+def test_uniform_path_variants(hp_mod, oracle, w, h, step, rect_scale, tile):
+    """Every instance of k_boxsum (aligned / unaligned loads, ring / re-read) and every region layout of
+    k_traverse's uniform path on frames wide enough for several tiles per row."""
+    forest = synth.synth_forest(6, 9, synth.FOREST_SEED_BASE + 300 + step, rect_scale=rect_scale)
+    model = synth.ModelParams(stepwidth=step)
+    frames = np.stack([synth.biwi_like(644, 480, 3100 + i)[:h, :w] for i in range(2)]).copy()
+    frames[1, :, : w // 2] = 0                      # half-empty frame: tiles skipped by their flags next to active ones
+    with env_override(**({"DH_TILE": tile} if tile else {})):
+        _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), full=False)
+    with env_override(DH_BOX_NO_RING=1, **({"DH_TILE": tile} if tile else {})):
+        if tile is None and step == 4 and rect_scale == 0.3:
+            _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), full=False)
 
 
 @pytest.mark.parametrize("general", [False, True])
