@@ -101,9 +101,14 @@ def main():
     distinct = synth.biwi_batch(nd, W, H, first=rank * nd)               # different frames on every rank
     frames_np = np.concatenate([distinct] * ((NF + nd - 1) // nd))[:NF]
     frames = torch.from_numpy(frames_np.view(np.int16)).to(dev)          # resident in HBM before timing
-    poses = torch.zeros(NF * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    # two pose buffers: the gather of step i (on RCCL's stream) overlaps the kernels of step i + 1, which
+    # therefore write the other buffer; a buffer is reused only after its gather has been waited for
+    pose_bufs = [torch.zeros(NF * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(2)]
+    poses = pose_bufs[0]
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
-    gathered = torch.zeros(world * NF * POSE_DTYPE.itemsize, dtype=torch.uint8, device=gdev) if world > 1 else None
+    gathered = [torch.zeros(world * NF * POSE_DTYPE.itemsize, dtype=torch.uint8, device=gdev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+    counter = [0]
 
     hp = HoughPrediction(forest, model, device=local_rank)
     hp.reserve(NF, W, H)
@@ -113,14 +118,24 @@ def main():
         hp.graph_capture(frames.data_ptr(), NF, W, H, intr, poses.data_ptr())
 
     def step():
+        b = counter[0] & 1 if (world > 1 and not args.graph) else 0
+        counter[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()                      # stream-side wait for NCCL; the buffer is free again
+            pending[b] = None
         if args.graph:
             hp.graph_launch(stream.cuda_stream)
         else:
-            hp.predict_batch_device(frames.data_ptr(), NF, W, H, intr, poses.data_ptr(), stream=stream.cuda_stream)
+            hp.predict_batch_device(frames.data_ptr(), NF, W, H, intr, pose_bufs[b].data_ptr(), stream=stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, poses if args.backend == "nccl" else poses.cpu())   # gather of the pose records
+            src = pose_bufs[b] if args.backend == "nccl" else pose_bufs[b].cpu()
+            pending[b] = dist.all_gather_into_tensor(gathered[b], src, async_op=True)   # gather of the pose records
 
     def fence():
+        for i in range(2):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
