@@ -894,12 +894,15 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             // the window is covered by rw x rh rectangles at offsets 0, rw, 2rw, ... (the last one
             // clamped to sw - rw); pixel values are non-negative, so the window sum is zero exactly
             // when every one of those rectangle sums is
+            // (window origins are multiples of m, so slot(origin + cover offset) = base(origin) + offset:
+            // the offsets are uniform and only the base is per lane)
             sum = 0;
+            const uint32_t *wp = sat + oy * ss + (ox >> a.swz_log2);
             for (int cyk = 0; cyk < a.sh; cyk += a.rh) {
-                const uint32_t *rowp = sat + (oy + min(cyk, a.sh - a.rh)) * ss;
+                const int ro = min(cyk, a.sh - a.rh) * ss;
                 for (int cxk = 0; cxk < a.sw; cxk += a.rw) {
-                    const int xc = ox + min(cxk, a.sw - a.rw);
-                    sum |= rowp[(xc & ((1 << a.swz_log2) - 1)) * a.swz_q + (xc >> a.swz_log2)];
+                    const int xc = min(cxk, a.sw - a.rw);
+                    sum |= wp[ro + (xc & ((1 << a.swz_log2) - 1)) * a.swz_q + (xc >> a.swz_log2)];
                 }
             }
         } else {

@@ -16,3 +16,9 @@ with HoughPrediction(forest, model, device=0) as hp:
         tr, st = hp.debug_meanshift(64, which)
         print(name, "steps: mean %.1f min %d max %d" % (st.mean(), st.min(), st.max()), np.bincount(st))
     print("hits per frame: mean %.0f min %d max %d" % (hc.mean(), hc.min(), hc.max()))
+    tr, st = hp.debug_meanshift(64, 1)
+    for i in range(4):
+        print("rot trace frame", i, tr[i].tolist())
+    tr, st = hp.debug_meanshift(64, 0)
+    for i in range(2):
+        print("mid trace frame", i, tr[i].tolist())
