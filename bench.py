@@ -209,6 +209,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": b_alg, "launch_ms": round(acc[dom], 4)},
             "kernels_ms": kernels,
+            # measured HBM traffic (PMC, gfx950-corrected) over the live duration of every kernel: shows which
+            # kernel actually runs at memory speed (k_boxsum) and which are latency / issue bound
+            "kernels_hbm": {KERNEL_OF[k]: {"traffic": t, "GB/s": round(t / (acc[k] * 1e-3) / 1e9, 1), "frac": round(t / (acc[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                            for k in KERNEL_OF for t in [pmc_traffic(KERNEL_OF[k])[0]] if t and acc[k] > 0},
             "pcie_inclusive_frames_per_s": None if pcie_fps is None else round(pcie_fps, 1),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -516,6 +516,22 @@ def test_randomized_differential(hp_mod, oracle):
             assert np.array_equal(poses["rotation"][i], ref.rotation), (tag, poses["rotation"][i], ref.rotation)
 
 
+@pytest.mark.parametrize("w,h,step", [(1280, 720, 4), (1000, 600, 5)])
+def test_frames_larger_than_vga(hp_mod, oracle, w, h, step):
+    """Frame sizes beyond BASELINE's: more tiles per row than VGA, three-plus column parts in k_boxsum,
+    a checkerboard of empty and occupied 640x480 blocks (tile flags next to each other)."""
+    forest = synth.synth_forest(5, 9, synth.FOREST_SEED_BASE + 77)
+    model = synth.ModelParams(stepwidth=step)
+    base = synth.biwi_like(640, 480, 4711)
+    frame = np.zeros((h, w), dtype=np.uint16)
+    for oy in range(0, h, 480):
+        for ox in range(0, w, 640):
+            hh, ww = min(480, h - oy), min(640, w - ox)
+            if (ox // 640 + oy // 480) % 2 == 0:
+                frame[oy:oy + hh, ox:ox + ww] = base[:hh, :ww]
+    _check_frames(hp_mod, oracle, forest, model, frame[None].copy(), synth.default_intrinsic(w, h), full=False)
+
+
 @pytest.mark.parametrize("sw,sh,w,h,step", [(250, 16, 640, 64, 16), (16, 250, 80, 480, 9), (190, 190, 300, 280, 5), (8, 8, 64, 48, 1)])
 def test_extreme_patch_shapes(hp_mod, oracle, sw, sh, w, h, step):
     """Very wide / very tall / near-maximal and tiny patches: tile geometry, segment counts and LDS
