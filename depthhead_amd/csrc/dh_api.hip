@@ -681,6 +681,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         va.f = p->dev; va.hits = p->hits + hoff; va.hit_box = p->hit_box + hoff; va.hit_rot = p->hit_rot + hoff;
         va.hit_count = hit_count; va.hits_cap = p->hits_cap;
         va.pos_grid = pos_grid; va.rot_grid = rot_grid;
+        va.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
         HIP_TRY(dh_launch_vote(va, s));
     }
     if (profile) HIP_TRY(hipEventRecord(p->ev[2], s));

@@ -1193,8 +1193,8 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
     uint32_t n = a.hit_count[frame];
     if (n > a.hits_cap) n = a.hits_cap;
     const uint32_t per = (n + VOTE_SLICES - 1) / VOTE_SLICES;
-    const uint32_t h0 = blockIdx.x * per, h1 = min(n, h0 + per);
-    if (h0 >= h1) return;
+    const uint32_t h0 = min(n, blockIdx.x * per), h1 = min(n, h0 + per);
+    if (n == 0 || (h0 >= h1 && !a.leaf_hits)) return;       // with the leaf histogram every slice also owns a share of the leaves
     for (int i = tid; i < DH_POSGRID; i += VOTE_THREADS) pos[i] = 0;
     for (int i = tid; i < DH_GRID3; i += VOTE_THREADS) rot[i] = 0;
     if (TAB) {
@@ -1214,7 +1214,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         const int4 b1 = ((const int4 *)(box + i))[1];
         const uint4 rr = *(const uint4 *)(hr + i);
         const uint32_t v = (uint32_t)b1.z, fc = (uint32_t)b1.w;
-        if (fc & LF_ROT)
+        if ((fc & LF_ROT) && !a.leaf_hits)
             for (uint32_t r = rr.z + sub; r < rr.z + (rr.w >> 16); r += VOTE_SUB) atomicAdd(&rot[a.f.rot_rough[r]], v * a.f.rough_mult[r]);   // :636
         if (fc & LF_OFF) {
             const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
@@ -1250,6 +1250,21 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
                 }
             }
             if (acc) atomicAdd(&pos[last], acc);
+        }
+    }
+    if (a.leaf_hits) {
+        // Rotation votes depend only on the leaf (prediction.rs:601-636): with the per-frame leaf histogram the
+        // 20^3 guess grid is the sum over the leaves that voted of count x v x (their distinct cells); u32
+        // wrap-around makes that the same residue as count separate adds.  The slices share the leaves.
+        const uint32_t *lh = a.leaf_hits + (size_t)frame * a.f.n_leaves;
+        for (uint32_t l = blockIdx.x * VOTE_THREADS + tid; l < a.f.n_leaves; l += VOTE_SLICES * VOTE_THREADS) {
+            const uint32_t c = lh[l];
+            if (!c) continue;
+            const uint4 *tp = (const uint4 *)(a.f.tpl + l);
+            const uint4 t1 = tp[1], t2 = tp[2], t3 = tp[3];
+            if (!(t1.w & LF_ROT)) continue;
+            const uint32_t cv = c * t1.z;                      // count x valtoadd
+            for (uint32_t r = t2.w; r < t2.w + (t3.x >> 16); ++r) atomicAdd(&rot[a.f.rot_rough[r]], cv * a.f.rough_mult[r]);   // :636
         }
     }
     __syncthreads();

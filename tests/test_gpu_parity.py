@@ -516,6 +516,38 @@ def test_randomized_differential(hp_mod, oracle):
             assert np.array_equal(poses["rotation"][i], ref.rotation), (tag, poses["rotation"][i], ref.rotation)
 
 
+def test_fewer_hits_than_vote_slices(hp_mod, oracle):
+    """Frames with 1..6 hit records (one or two windows, three single-split trees whose leaves all
+    vote): most of k_vote's 8 slices get no record but still own their share of the leaf histogram
+    (rotation guess grid)."""
+    nodes = np.zeros(3, dtype=NODE_DTYPE)
+    nodes[0] = ((4, 4, 28, 28), (40, 40, 64, 64), 0.0, ~0, ~1)
+    nodes[1] = ((10, 30, 34, 54), (44, 6, 68, 30), 10.0, ~2, ~3)
+    nodes[2] = ((0, 0, 24, 24), (56, 56, 80, 80), -5.0, ~4, ~5)
+    roots = np.array([0, 1, 2], dtype=np.int32)
+    prob = np.array([1.0, 0.9, 0.95, 1.0, 0.8, 1.0])
+    rs = np.random.RandomState(7)
+    noff = [3, 4, 3, 5, 3, 4]
+    begin = np.concatenate([[0], np.cumsum(noff)]).astype(np.uint32)
+    offsets = (rs.uniform(-40, 40, (int(begin[-1]), 3)) + np.repeat(rs.uniform(-60, 60, (6, 3)), noff, axis=0)).astype(np.float32)
+    rotations = rs.uniform(-3, 3, (int(begin[-1]), 3)) + np.repeat(rs.uniform(-40, 40, (6, 3)), noff, axis=0)
+    forest = Forest(roots, nodes, prob, begin, begin.copy(), offsets, rotations)
+    base = synth.biwi_like(640, 480, 777)
+    ys, xs = np.nonzero(base)
+    cy, cx = int(ys.mean()), int(xs.mean())
+    seen = set()
+    for w in (84, 88):                                                 # one window, two windows (the loops are exclusive, :546-548)
+        frame = base[cy - 42:cy + 42, cx - 40:cx - 40 + w].copy()
+        model = synth.ModelParams(stepwidth=4)
+        K = synth.default_intrinsic(w, 84)
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            hp.debug_enable(True)
+            hp.predict_batch(frame[None].copy(), hp_mod.IntrinsicMatrix(K))
+            seen.add(int(hp.debug_hit_counts(1)[0]))
+        _check_frames(hp_mod, oracle, forest, model, frame[None].copy(), K, full=False)
+    assert seen & set(range(1, 8)), f"hit counts {seen}: expected a frame with 1..7 records"
+
+
 @pytest.mark.parametrize("w,h,step", [(1280, 720, 4), (1000, 600, 5)])
 def test_frames_larger_than_vga(hp_mod, oracle, w, h, step):
     """Frame sizes beyond BASELINE's: more tiles per row than VGA, three-plus column parts in k_boxsum,
