@@ -1175,7 +1175,9 @@ hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream
 // one frame's hit records, accumulates in LDS and flushes its non-zero cells with integer atomics
 // (exact, order-free, wrapping like the reference's release-mode u32 `+=`).
 #define VOTE_THREADS 512
+#ifndef VOTE_SLICES
 #define VOTE_SLICES 8
+#endif
 #define VOTE_TAB 2048
 #ifndef VOTE_SUB
 #define VOTE_SUB 4u              // lanes that share one hit record (measured on MI355X: 4 x 12 beats 8 x 6 by 9 %, 2 x 12 by 4 %)
@@ -1212,7 +1214,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
     for (uint32_t i = h0 + tid / VOTE_SUB; i < h1; i += VOTE_THREADS / VOTE_SUB) {
         const float4 rec = *(const float4 *)(hits + i);
         const int4 b1 = ((const int4 *)(box + i))[1];
-        const uint4 rr = *(const uint4 *)(hr + i);
+        const uint4 rr = a.leaf_hits ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4 *)(hr + i);   // rotation cells: only without the leaf histogram
         const uint32_t v = (uint32_t)b1.z, fc = (uint32_t)b1.w;
         if ((fc & LF_ROT) && !a.leaf_hits)
             for (uint32_t r = rr.z + sub; r < rr.z + (rr.w >> 16); r += VOTE_SUB) atomicAdd(&rot[a.f.rot_rough[r]], v * a.f.rough_mult[r]);   // :636
