@@ -627,7 +627,6 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         TraverseArgs ta{};
         ta.frames = fr; ta.n_frames = n; ta.w = w; ta.h = h;
         ta.step = (int)p->params.stepwidth; ta.sw = (int)p->params.subimage_width; ta.sh = (int)p->params.subimage_height;
-        ta.lw = ta.sw / 2; ta.lh = ta.sh / 2;
         ta.nx = g.nx; ta.ny = g.ny; ta.px = g.px; ta.py = g.py; ta.tiles_x = g.tiles_x; ta.tiles_y = g.tiles_y;
         ta.ss_max = g.ss_max; ta.ss_row = g.ss_row; ta.swz_log2 = g.swz_log2; ta.swz_q = g.swz_q;
         ta.uniform = g.uniform ? 1 : 0; ta.rw = p->f_rw; ta.rh = p->f_rh; ta.area = (uint32_t)(p->f_rw * p->f_rh);
@@ -641,13 +640,11 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
             else {
                 unsigned long long hst[8];
                 HIP_TRY(hipMemcpy(hst, stamps, 64, hipMemcpyDeviceToHost));
-                fprintf(stderr, "[k_traverse cycles/phase summed over workgroups] A=%llu stitchV=%llu horiz=%llu gate=%llu box=%llu walk=%llu tail=%llu\n",
-                        hst[0], hst[1], hst[2], hst[3], hst[4], hst[5], hst[6]);
+                fprintf(stderr, "[k_traverse cycles/phase summed over the workgroups that reach it] region=%llu gate=%llu walks=%llu\n", hst[0], hst[1], hst[2]);
                 HIP_TRY(hipMemset(stamps, 0, 64));
             }
             ta.dbg_stamps = stamps;
         }
-        memcpy(ta.kinv, kinv, 9 * sizeof(float));
         ta.f = p->dev;
         const int tiles = g.tiles_x * g.tiles_y;
         uint32_t *win_count = p->counters + (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words) + (size_t)f0 * tiles;
@@ -660,7 +657,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         if (!traverse_only) {
             EmitArgs ea{};
             ea.frames = fr; ea.n_frames = n; ea.w = w; ea.h = h;
-            ea.step = ta.step; ea.lw = ta.lw; ea.lh = ta.lh; ea.nx = g.nx; ea.npatch = g.npatch;
+            ea.step = ta.step; ea.lw = ta.sw / 2; ea.lh = ta.sh / 2; ea.nx = g.nx; ea.npatch = g.npatch;
             ea.px = g.px; ea.py = g.py; ea.tiles = tiles;
             memcpy(ea.kinv, kinv, 9 * sizeof(float));
             ea.f = p->dev;

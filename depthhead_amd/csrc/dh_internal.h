@@ -82,7 +82,7 @@ struct __attribute__((aligned(16))) HitRot {
 struct TraverseArgs {
     const uint16_t *frames;
     int n_frames, w, h;
-    int step, sw, sh, lw, lh;
+    int step, sw, sh;
     int nx, ny;             // patch grid
     int px, py;             // tile size in patches
     int tiles_x, tiles_y;
@@ -96,9 +96,8 @@ struct TraverseArgs {
     int box_plane, box_rows;
     const uint8_t *tile_flags; // uniform path: [n_frames][tiles] 1 = the tile's region holds a non-zero box sum (k_boxsum)
     const void *nodes_u;    // NodeU[n_nodes], built by k_nodes_compact for this region layout
-    unsigned long long *dbg_stamps; // profiling: [8] summed cycles per phase over all workgroups (env DH_TRAV_STAMPS)
-    int stop_phase;         // profiling knob (env DH_TRAV_STOP): 0 = run everything, k = return after phase k
-    float kinv[9];
+    unsigned long long *dbg_stamps; // profiling: [8] summed cycles per phase (region build, gate, walks) over all workgroups (env DH_TRAV_STAMPS)
+    int stop_phase;         // profiling knob (env DH_TRAV_STOP): 0 = run everything, 9 / 1 / 3 = return at entry / after the region build / after the gate
     DevForest f;
     // window list (read by k_emit): tile t owns slots [t * px * py, t * px * py + win_count[frame][t])
     uint32_t *win_count;    // [n_frames][tiles] active windows per tile (zeroed per batch by the host)

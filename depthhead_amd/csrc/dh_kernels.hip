@@ -878,9 +878,6 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     }
     if (a.stop_phase == 1) return;
     STAMP(0)
-    STAMP(1)
-    if (a.stop_phase == 2) return;
-    STAMP(2)
 
     // ---- phase 2: background gate (prediction.rs:567-571).  Active windows are appended to the tile's
     // segment of the frame's window list (a fixed px * py slots per tile, so no global counter is needed).
@@ -929,12 +926,11 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     }
     __syncthreads();
     if (a.stop_phase == 3) return;
-    STAMP(3)
+    STAMP(1)
     const int n_active = (int)misc[0];
     if (tid == 0) a.win_count[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] = (uint32_t)n_active;   // zero for skipped tiles (host memset)
     if (n_active == 0) return;     // nothing to walk (debug taps were written above)
 
-    STAMP(4)
     // ---- phase 3: root->leaf walks.  Work item k = (tree k / n_active, active slot k % n_active),
     // lane = k mod 1024: the lanes of a wave walk the SAME tree for NEIGHBOURING windows (4 px apart),
     // which see almost the same pixels, so they mostly follow the same path: node fetches collapse
@@ -981,7 +977,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         }
     }
 
-    STAMP(5)
+    STAMP(2)
 }
 
 // ================================================================== k_emit
