@@ -895,11 +895,17 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             // the offsets are uniform and only the base is per lane)
             sum = 0;
             const uint32_t *wp = sat + oy * ss + (ox >> a.swz_log2);
-            for (int cyk = 0; cyk < a.sh; cyk += a.rh) {
-                const int ro = min(cyk, a.sh - a.rh) * ss;
-                for (int cxk = 0; cxk < a.sw; cxk += a.rw) {
-                    const int xc = min(cxk, a.sw - a.rw);
-                    sum |= wp[ro + (xc & ((1 << a.swz_log2) - 1)) * a.swz_q + (xc >> a.swz_log2)];
+            const int ncx = (a.sw + a.rw - 1) / a.rw, ncy = (a.sh + a.rh - 1) / a.rh;
+            for (int iy = 0; iy < ncy; ++iy) {
+                const int ro = min(iy * a.rh, a.sh - a.rh) * ss;
+                for (int ix = 0; ix < ncx; ix += 4) {               // four reads in flight
+                    uint32_t v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int xc = min(min(ix + k, ncx - 1) * a.rw, a.sw - a.rw);
+                        v[k] = wp[ro + (xc & ((1 << a.swz_log2) - 1)) * a.swz_q + (xc >> a.swz_log2)];
+                    }
+                    sum |= v[0] | v[1] | v[2] | v[3];
                 }
             }
         } else {
@@ -916,7 +922,6 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             const uint32_t slot = wave_base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             active[slot] = (uint32_t)tid;
             agp[slot] = (uint32_t)gp;
-            wpatch[slot] = (uint32_t)gp;
         }
         if (a.dbg_flags) {
             a.dbg_flags[(size_t)frame * a.nx * a.ny + gp] = nonbg ? 1 : 0;
@@ -930,6 +935,8 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     const int n_active = (int)misc[0];
     if (tid == 0) a.win_count[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] = (uint32_t)n_active;   // zero for skipped tiles (host memset)
     if (n_active == 0) return;     // nothing to walk (debug taps were written above)
+    // the window list's positions: stored after the barrier so that nothing waits for the stores
+    if (tid < n_active) wpatch[tid] = agp[tid];
 
     // ---- phase 3: root->leaf walks.  Work item k = (tree k / n_active, active slot k % n_active),
     // lane = k mod 1024: the lanes of a wave walk the SAME tree for NEIGHBOURING windows (4 px apart),
