@@ -493,12 +493,12 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
     g.tiles_x = (g.nx + g.px - 1) / g.px;
     g.tiles_y = (g.ny + g.py - 1) / g.py;
     g.win_cap = g.tiles_x * g.tiles_y * g.px * g.py;
+    g.flag_words = (g.tiles_x * g.tiles_y + 3) / 4;
     g.ss_row = dh_traverse_row_stride(g.px, step, sw, rw);
     if (rw > 0) dh_traverse_swizzle(g.px, step, sw, rw, &g.swz_log2, &g.swz_q, &g.ss_row);
     g.ss_max = g.ss_row * ((g.py - 1) * step + sh + (rw > 0 ? 1 - rh : 1));
     if (rw > 0) {
         g.box_rows = g.h - rh + 1;
-        g.flag_words = (g.tiles_x * g.tiles_y + 3) / 4;
         // a row of the image = m planes (same de-interleave as the LDS region) of box_plane words;
         // the slack lets a tile read whole 16-byte groups past its last column
         const int m = 1 << g.swz_log2;
@@ -621,6 +621,15 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         }
         ba.blocks_per_frame = (ba.parts * ba.bands + 3) / 4;
         HIP_TRY(dh_launch_boxsum(ba, s));
+    }
+    if (g.npatch > 0 && !g.uniform) {
+        PixFlagArgs fa{};
+        fa.frames = fr; fa.n_frames = n; fa.w = w; fa.h = h; fa.tile_flags = tile_flags;
+        fa.tiles_x = g.tiles_x; fa.tiles_y = g.tiles_y;
+        fa.tpx = g.px * (int)p->params.stepwidth; fa.tpy = g.py * (int)p->params.stepwidth;
+        fa.tfw = (g.px - 1) * (int)p->params.stepwidth + (int)p->params.subimage_width;
+        fa.tfh = (g.py - 1) * (int)p->params.stepwidth + (int)p->params.subimage_height;
+        HIP_TRY(dh_launch_pixflags(fa, s));
     }
     if (profile) HIP_TRY(hipEventRecord(p->ev[4], s));
     if (g.npatch > 0) {

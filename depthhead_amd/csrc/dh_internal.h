@@ -94,7 +94,7 @@ struct TraverseArgs {
     int swz_log2, swz_q;    // uniform path: LDS slot of region cell (y, x) = y * ss_row + (x & (m - 1)) * swz_q + (x >> swz_log2), m = 1 << swz_log2
     const uint32_t *box;    // uniform path: [n_frames][box_rows][m planes][box_plane] box-sum images written by k_boxsum
     int box_plane, box_rows;
-    const uint8_t *tile_flags; // uniform path: [n_frames][tiles] 1 = the tile's region holds a non-zero box sum (k_boxsum)
+    const uint8_t *tile_flags; // [n_frames][tiles] 1 = the tile's region holds a non-zero box sum (k_boxsum) / its footprint a non-zero pixel (k_pixflags)
     const void *nodes_u;    // NodeU[n_nodes], built by k_nodes_compact for this region layout
     unsigned long long *dbg_stamps; // profiling: [8] summed cycles per phase (region build, gate, walks) over all workgroups (env DH_TRAV_STAMPS)
     int stop_phase;         // profiling knob (env DH_TRAV_STOP): 0 = run everything, 9 / 1 / 3 = return at entry / after the region build / after the gate
@@ -146,6 +146,15 @@ struct BoxArgs {
     int parts, bands;       // waves across / down a frame
     int blocks_per_frame;   // ceil(parts * bands / 4)
     int ring;               // 1: keep the rh - 1 window rows in a wave-private LDS ring (rh - 1 <= 28) instead of re-reading them
+};
+
+// k_pixflags: tile flags of the general path (non-zero pixel under the tile's footprint).
+struct PixFlagArgs {
+    const uint16_t *frames;
+    int n_frames, w, h;
+    uint8_t *tile_flags;    // [n_frames][tiles_x * tiles_y], zeroed per batch by the host
+    int tiles_x, tiles_y;   // tile (tx, ty) covers pixel columns [tx * tpx, tx * tpx + tfw), rows [ty * tpy, ty * tpy + tfh)
+    int tpx, tpy, tfw, tfh;
 };
 
 struct VoteArgs {
@@ -225,6 +234,7 @@ hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s);
 hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s);
 hipError_t dh_launch_votes_dump(const VotesDumpArgs &a, hipStream_t s);
 hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s);
+hipError_t dh_launch_pixflags(const PixFlagArgs &a, hipStream_t s);
 // rw, rh > 0 selects the uniform (box-sum region) layout, 0 the general (SAT) layout
 size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees, int rw, int rh);
 int dh_traverse_row_stride(int px, int step, int sw, int rw);

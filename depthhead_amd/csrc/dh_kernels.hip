@@ -554,6 +554,44 @@ __device__ __forceinline__ bool sat_passes(uint32_t *sat, uint32_t *flag, const 
     return true;
 }
 
+// ================================================================== k_pixflags
+// General (mixed-rectangle) path: which k_traverse tiles have a non-zero pixel under their footprint?
+// One workgroup scans a band of 32 image rows of one frame (8-byte loads, 4 columns per lane); a lane
+// that saw a non-zero pixel marks the tiles whose footprints contain its columns and the band's rows
+// (plain stores of 1; the flags are zeroed per batch).  Conservative by construction.
+__global__ void __launch_bounds__(256) k_pixflags(PixFlagArgs a) {
+    const int frame = (int)blockIdx.z * 8 + (int)blockIdx.x;
+    if (frame >= a.n_frames) return;
+    const int y0 = (int)blockIdx.y * 32, y1 = min(y0 + 32, a.h);
+    const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
+    uint8_t *flags = a.tile_flags + (size_t)frame * a.tiles_x * a.tiles_y;
+    const float r_tpx = 1.0f / (float)a.tpx, r_tpy = 1.0f / (float)a.tpy;
+    const bool al = (a.w & 3) == 0 && (((size_t)a.frames) & 7) == 0;
+    for (int x = 4 * (int)threadIdx.x; x < a.w; x += 4 * 256) {
+        uint32_t acc = 0;
+        if (al) {
+            for (int y = y0; y < y1; ++y) { const uint2 q = *(const uint2 *)(img + (size_t)y * a.w + x); acc |= q.x | q.y; }
+        } else {
+            for (int y = y0; y < y1; ++y)
+                for (int c = 0; c < 4 && x + c < a.w; ++c) acc |= img[(size_t)y * a.w + x + c];
+        }
+        if (!acc) continue;
+        // tile tx covers pixel columns [tx * tpx, tx * tpx + tfw), rows likewise
+        const int tx1 = min(div_small(min(x + 3, a.w - 1), a.tpx, r_tpx), a.tiles_x - 1), tx0 = x - a.tfw < 0 ? 0 : div_small(x - a.tfw, a.tpx, r_tpx) + 1;
+        const int ty1 = min(div_small(y1 - 1, a.tpy, r_tpy), a.tiles_y - 1), ty0 = y0 - a.tfh < 0 ? 0 : div_small(y0 - a.tfh, a.tpy, r_tpy) + 1;
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) flags[ty * a.tiles_x + tx] = 1;
+    }
+}
+
+hipError_t dh_launch_pixflags(const PixFlagArgs &a, hipStream_t s) {
+    const int fb = (a.n_frames + 7) / 8, bands = (a.h + 31) / 32;
+    if (fb == 0 || bands == 0) return hipSuccess;
+    if (bands > 65535 || fb > 65535) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_pixflags, dim3(8, bands, fb), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // ================================================================== k_boxsum
 // Uniform-rectangle forests (the trainer's geometry, types.rs:82-91): every split test compares the
 // sums of two rw x rh rectangles, so the image of ALL such sums is computed once per frame here
@@ -817,12 +855,10 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // (k_boxsum): cell (y, x) = sum of the rw x rh rectangle whose top-left pixel is (fx0 + x, fy0 + y).
     // this thread's window (one per thread: npt <= 1024)
     const int wy = div_small(tid, cx, r_cx), wx = tid - wy * cx;
-    bool nonzero = true;
-    if (UNI) {
-        // k_boxsum flagged the tiles whose region holds a non-zero rectangle sum; any other tile has only
-        // background windows and leaves before copying anything
-        nonzero = a.tile_flags[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] != 0;
-    }
+    // k_boxsum (uniform path) / k_pixflags (general path) flagged the tiles whose region holds a non-zero
+    // rectangle sum / whose footprint holds a non-zero pixel; any other tile has only background windows
+    // (prediction.rs:567-576) and leaves before building anything
+    bool nonzero = a.tile_flags[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] != 0;
     if (tid < 8) misc[tid] = 0;
     __syncthreads();
     if (UNI && nonzero) {
@@ -857,7 +893,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         }
         __syncthreads();
     }
-    if (!UNI) {
+    if (!UNI && nonzero) {
         const int strip = (fh + TRAV_WAVES - 1) / TRAV_WAVES;
         if (fw <= 2 * WAVE && strip <= 8) nonzero = sat_rows_dpp<2>(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
         else if (fw <= 4 * WAVE && strip <= 4) nonzero = sat_rows_dpp<4>(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
