@@ -251,7 +251,8 @@ struct dh_predictor {
     uint32_t *box = nullptr;         // [cap][box_rows][m][box_plane] rectangle-sum images (uniform path)
     uint32_t *win_patch = nullptr;   // [cap][win_cap] window list: position in the window grid
     int32_t *win_leaf = nullptr;     // [cap][T][win_cap] window list: leaf per tree
-    uint32_t *leaf_hits = nullptr;   // [cap][n_leaves] rotation-vote histogram, only for forests of <= DH_LEAF_HIST_MAX leaves
+    uint32_t *leaf_hits = nullptr;   // [cap][n_leaves] rotation-vote histogram (inside `counters`), only for forests of <= DH_LEAF_HIST_MAX leaves
+    size_t zero_words = 0;           // words of `counters` zeroed before every batch
     uint32_t hits_cap = 0;
     uint32_t *counters = nullptr;    // [n] hit_count | [n][400] pos_grid | [n][8000] rot_grid (one memset)
     dh_pose *ws_poses = nullptr;
@@ -333,11 +334,11 @@ static int build_kernel_table(dh_predictor *p) {
 }
 
 static void free_workspace(dh_predictor *p) {
-    void *ptrs[] = {p->box, p->win_patch, p->win_leaf, p->leaf_hits, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
+    void *ptrs[] = {p->box, p->win_patch, p->win_leaf, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
                     p->dbg_flags, p->dbg_guess, p->dbg_trace, p->dbg_steps, p->dbg_votes, p->dbg_vcount};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    p->box = nullptr; p->win_patch = nullptr; p->win_leaf = nullptr; p->leaf_hits = nullptr;
+    p->box = nullptr; p->win_patch = nullptr; p->win_leaf = nullptr; p->leaf_hits = nullptr; p->zero_words = 0;
     p->aux_leaf = nullptr; p->aux_flags = nullptr; p->aux_u32 = nullptr; p->aux_out = nullptr; p->aux_out_bytes = 0; p->aux_cap = 0;
     p->ws_frames = nullptr; p->hits = nullptr; p->hit_box = nullptr; p->hit_rot = nullptr; p->counters = nullptr; p->ws_poses = nullptr; p->ws_midp = nullptr;
     p->ws_rot = nullptr; p->ws_mask = nullptr; p->dbg_leaf = nullptr; p->dbg_flags = nullptr; p->dbg_guess = nullptr;
@@ -552,8 +553,12 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
         STEP(dev_alloc(p, &p->box, words));
         if (rc == DH_OK && hipMemset(p->box, 0, words * sizeof(uint32_t)) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box)");   // the slack columns stay 0
     }
-    if (p->n_leaves <= DH_LEAF_HIST_MAX && !getenv("DH_NO_LEAF_HIST")) STEP(dev_alloc(p, &p->leaf_hits, (size_t)cap * p->n_leaves));
-    STEP(dev_alloc(p, &p->counters, (size_t)cap * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words + (size_t)g.tiles_x * g.tiles_y)));
+    // one block, one memset per batch: hit counters | guess grids | tile flags | window counts | leaf histogram
+    const bool leaf_hist = p->n_leaves <= DH_LEAF_HIST_MAX && !getenv("DH_NO_LEAF_HIST");
+    const size_t counter_words = (size_t)cap * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words + (size_t)g.tiles_x * g.tiles_y);
+    STEP(dev_alloc(p, &p->counters, counter_words + (leaf_hist ? (size_t)cap * p->n_leaves : 0)));
+    if (rc == DH_OK) p->leaf_hits = leaf_hist ? p->counters + counter_words : nullptr;
+    p->zero_words = counter_words + (leaf_hist ? (size_t)cap * p->n_leaves : 0);
     STEP(dev_alloc(p, &p->ws_poses, cap));
     STEP(dev_alloc(p, &p->ws_midp, (size_t)cap * 3));
     STEP(dev_alloc(p, &p->ws_rot, (size_t)cap * 3));
@@ -739,8 +744,7 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
     mat3_inv_f32(K, kinv);   // cached in a RefCell by the reference (types.rs:436-441)
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
-        HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3 + (size_t)p->geom.flag_words + (size_t)p->geom.tiles_x * p->geom.tiles_y) * sizeof(uint32_t), s));
-        if (p->leaf_hits) HIP_TRY(hipMemsetAsync(p->leaf_hits, 0, (size_t)m * p->n_leaves * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(p->counters, 0, p->zero_words * sizeof(uint32_t), s));
         const uint16_t *fr = frames + (size_t)f0 * w * h;
         const float *mg = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
         const double *rg = rot_guess ? rot_guess + (size_t)f0 * 3 : nullptr;
