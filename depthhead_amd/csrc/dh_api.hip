@@ -705,6 +705,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ca.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
         ca.pos_grid = pos_grid; ca.rot_grid = rot_grid; ca.kern_ord = p->kern_ord;
         ca.iterations = p->params.meanshift_iterations;
+        if (const char *e = getenv("DH_CL_STOP")) ca.stop = atoi(e);
         ca.midp_guess = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
         ca.rot_guess = rot_guess ? rot_guess + (size_t)f0 * 3 : nullptr;
         ca.guess_mask = guess_mask ? guess_mask + f0 : nullptr;

@@ -193,6 +193,7 @@ struct ClusterArgs {
     int32_t  *dbg_guess;       // nullable [n][6]
     int32_t  *dbg_trace;       // nullable [2][n][iterations+1][3]
     uint32_t *dbg_steps;       // nullable [2][n]
+    int stop;               // profiling knob (env DH_CL_STOP): 1 / 2 / 3 = return after the initial guess / the first region build / the first weighted sum
 };
 
 struct VotesDumpArgs {

@@ -1338,6 +1338,7 @@ hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
 #define CL_WAVES (CL_THREADS / WAVE)
 #define CL_CHUNKS 8             // 8 * 1024 = 8192 >= 8000 window cells
 #define CL_PROD_CAP 512         // products staged per pass (x4 floats = 8 KB)
+#define CL_LIST (CL_PROD_CAP * 4) // hit records tested per pass of the position gather (their survivors are listed in `prod`)
 #define RG 26                   // region edge; the window may sit at offsets 0..RG-20 inside it
 #define RG3 (RG * RG * RG)
 
@@ -1425,6 +1426,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
     int32_t *trace = a.dbg_trace ? a.dbg_trace + ((size_t)which * a.n_frames + frame) * (a.iterations + 1) * 3 : nullptr;
     if (trace && tid < 3) trace[tid] = pos[tid];
 
+    if (a.stop == 1) return;
     // ---------------- mean shift (meanshift.rs:328-407)
     uint32_t n_hits = a.hit_count[frame];
     if (n_hits > a.hits_cap) n_hits = a.hits_cap;
@@ -1447,26 +1449,32 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
             __syncthreads();
             if (which == 0) {
-                for (uint32_t i0 = 0; i0 < n_hits; i0 += CL_THREADS * 2) {
-                    int4 b0[2], b1[2];
-                    float4 rec[2];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        uint32_t i = i0 + j * CL_THREADS + tid;
-                        b1[j].w = 0;
-                        if (i < n_hits) { b0[j] = ((const int4 *)(box + i))[0]; b1[j] = ((const int4 *)(box + i))[1]; rec[j] = *(const float4 *)(hits + i); }
+                // Two steps per chunk of CL_LIST hit records: (1) every thread tests the vote bounding boxes of
+                // its records against the region and appends the survivors to a list (in `prod`, idle now);
+                // (2) 16 lanes share each surviving record and take its offset votes 16 apart, so the chain
+                // of dependent vote loads per lane is n_votes / 16 long instead of n_votes.
+                uint32_t *list = (uint32_t *)prod;
+                for (uint32_t c0 = 0; c0 < n_hits; c0 += CL_LIST) {
+                    if (tid == 0) s_total = 0;
+                    __syncthreads();
+                    const uint32_t c1 = min(n_hits, c0 + CL_LIST);
+                    for (uint32_t i = c0 + tid; i < c1; i += CL_THREADS) {
+                        const int4 b0 = ((const int4 *)(box + i))[0], b1 = ((const int4 *)(box + i))[1];
+                        const uint32_t fc = (uint32_t)b1.w;
+                        if ((fc & LF_OFF) && range_hits_span(b0.x, b0.w, org[0], RG) && range_hits_span(b0.y, b1.x, org[1], RG) &&
+                            range_hits_span(b0.z, b1.y, org[2], RG))
+                            list[atomicAdd(&s_total, 1u)] = i;
                     }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const uint32_t fc = (uint32_t)b1[j].w;
-                        if (!(fc & LF_OFF)) continue;
-                        if (!range_hits_span(b0[j].x, b0[j].w, org[0], RG)) continue;
-                        if (!range_hits_span(b0[j].y, b1[j].x, org[1], RG)) continue;
-                        if (!range_hits_span(b0[j].z, b1[j].y, org[2], RG)) continue;
-                        const uint32_t v = (uint32_t)b1[j].z, ob = __float_as_uint(rec[j].w), oe = ob + (fc >> 8);
-                        for (uint32_t o = ob; o < oe; ++o) {
+                    __syncthreads();
+                    const uint32_t np = s_total;
+                    for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) {
+                        const uint32_t i = list[k >> 4], sub = k & 15u;
+                        const float4 rec = *(const float4 *)(hits + i);
+                        const uint32_t v = box[i].v, fc = box[i].fc;
+                        const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
+                        for (uint32_t o = ob + sub; o < oe; o += 16u) {
                             const float *of = a.f.offsets + (size_t)o * 3;
-                            float nx = __fsub_rn(rec[j].x, of[0]), ny = __fsub_rn(rec[j].y, of[1]), nz = __fsub_rn(rec[j].z, of[2]); // prediction.rs:647
+                            float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // prediction.rs:647
                             if (nz < 0.0f) continue;                                                                      // :650
                             uint32_t dx = (uint32_t)f32_as_i32(nx) - (uint32_t)org[0];                                     // :667
                             uint32_t dy = (uint32_t)f32_as_i32(ny) - (uint32_t)org[1];
@@ -1474,6 +1482,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                             if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], v);
                         }
                     }
+                    __syncthreads();
                 }
             } else if (a.leaf_hits) {
                 // Rotation votes depend only on the leaf (prediction.rs:601-636): the accumulator is
@@ -1481,36 +1490,37 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                 // the leaves that voted at all instead of every hit -- u32 wrap-around makes
                 // hits * v * mult the same residue as that many separate adds.
                 const uint32_t *lh = a.leaf_hits + (size_t)frame * a.f.n_leaves;
-                for (uint32_t l0 = 0; l0 < a.f.n_leaves; l0 += CL_THREADS * 4) {
-                    uint32_t c[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { const uint32_t l = l0 + j * CL_THREADS + tid; c[j] = l < a.f.n_leaves ? lh[l] : 0u; }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (!c[j]) continue;
-                        const uint4 *tp = (const uint4 *)(a.f.tpl + (l0 + j * CL_THREADS + tid));
-                        const uint4 t1 = tp[1], t2 = tp[2], t3 = tp[3];
+                uint32_t *list = (uint32_t *)prod;                    // same two-step scheme as the position gather
+                for (uint32_t c0 = 0; c0 < a.f.n_leaves; c0 += CL_LIST) {
+                    if (tid == 0) s_total = 0;
+                    __syncthreads();
+                    const uint32_t c1 = min(a.f.n_leaves, c0 + CL_LIST);
+                    for (uint32_t l = c0 + tid; l < c1; l += CL_THREADS) {
+                        if (!lh[l]) continue;
+                        const uint4 t2 = ((const uint4 *)(a.f.tpl + l))[2];
                         const uint32_t bl = t2.y, bh = t2.z;
                         if (bl == 0xFFFFFFFFu) continue;
-                        if (!range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG)) continue;
-                        if (!range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG)) continue;
-                        if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG)) continue;
-                        const uint32_t v = c[j] * t1.z, q1 = t2.w + (t3.x & 0xffffu);
-                        for (uint32_t q0 = t2.w; q0 < q1; q0 += 4) {   // 4 cells in flight: the loads do not depend on each other
-                            uint32_t bb[4], mm[4];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) { const uint32_t qi = min(q0 + k, q1 - 1); bb[k] = a.f.rot_bin[qi]; mm[k] = a.f.rot_mult[qi]; }
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                if (q0 + k >= q1) break;
-                                const uint32_t b = bb[k], vm = v * mm[k];                                                  // prediction.rs:635
-                                uint32_t dx = (b & 255u) - (uint32_t)org[0];
-                                uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
-                                uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
-                                if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
-                            }
+                        if (range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG) &&
+                            range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG) &&
+                            range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG))
+                            list[atomicAdd(&s_total, 1u)] = l;
+                    }
+                    __syncthreads();
+                    const uint32_t np = s_total;
+                    for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) {
+                        const uint32_t l = list[k >> 4], sub = k & 15u;
+                        const uint4 *tp = (const uint4 *)(a.f.tpl + l);
+                        const uint4 t1 = tp[1], t2 = tp[2], t3 = tp[3];
+                        const uint32_t v = lh[l] * t1.z, q1 = t2.w + (t3.x & 0xffffu);   // times the leaf voted x valtoadd
+                        for (uint32_t q = t2.w + sub; q < q1; q += 16u) {
+                            const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                  // prediction.rs:635
+                            uint32_t dx = (b & 255u) - (uint32_t)org[0];
+                            uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
+                            uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
+                            if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
                         }
                     }
+                    __syncthreads();
                 }
             } else {
                 for (uint32_t i0 = 0; i0 < n_hits; i0 += CL_THREADS * 2) {
@@ -1542,6 +1552,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             }
         }
         __syncthreads();
+        if (a.stop == 2) return;
         // ---- order-preserving compaction of the window's non-zero cells; window cell index
         // (dx*20+dy)*20+dz = chunk*1024 + tid is the reference's summation order
 #pragma unroll 1
@@ -1602,6 +1613,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             }
             __syncthreads();
         }
+        if (a.stop == 3) return;
         const float den = s_acc[3];
         if (den == 0.0f) break;                                                              // :385-388
         int32_t np0 = f32_as_i32(__fdiv_rn(s_acc[0], den)), np1 = f32_as_i32(__fdiv_rn(s_acc[1], den)),
