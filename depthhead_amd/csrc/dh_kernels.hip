@@ -1338,7 +1338,7 @@ hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
 #define CL_WAVES (CL_THREADS / WAVE)
 #define CL_CHUNKS 8             // 8 * 1024 = 8192 >= 8000 window cells
 #define CL_PROD_CAP 512         // products staged per pass (x4 floats = 8 KB)
-#define CL_LIST (CL_PROD_CAP * 4) // hit records tested per pass of the position gather (their survivors are listed in `prod`)
+#define CL_LIST (CL_PROD_CAP * 4) // survivors of the region gathers' bounding-box tests listed in `prod` (2048)
 #define RG 26                   // region edge; the window may sit at offsets 0..RG-20 inside it
 #define RG3 (RG * RG * RG)
 
@@ -1347,6 +1347,25 @@ hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
 __device__ __forceinline__ bool range_hits_span(int32_t lo, int32_t hi, int32_t start, uint32_t len) {
     uint32_t u = (uint32_t)start - (uint32_t)lo;
     return u <= (uint32_t)hi - (uint32_t)lo || u >= (uint32_t)(1u - len);
+}
+
+// Position votes of hit record i that fall into the region: lane `sub` of `nsub` takes the leaf's offset votes
+// sub, sub + nsub, ... (prediction.rs:647-667).
+__device__ __forceinline__ void cluster_add_votes(const ClusterArgs &a, uint32_t *region, const HitRec *hits, const HitBox *box,
+                                                  uint32_t i, uint32_t sub, uint32_t nsub, const int32_t org[3]) {
+    const float4 rec = *(const float4 *)(hits + i);
+    const uint32_t v = box[i].v, fc = box[i].fc;
+    const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
+#pragma unroll 1
+    for (uint32_t o = ob + sub; o < oe; o += nsub) {
+        const float *of = a.f.offsets + (size_t)o * 3;
+        float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // prediction.rs:647
+        if (nz < 0.0f) continue;                                                                      // :650
+        uint32_t dx = (uint32_t)f32_as_i32(nx) - (uint32_t)org[0];                                     // :667
+        uint32_t dy = (uint32_t)f32_as_i32(ny) - (uint32_t)org[1];
+        uint32_t dz = (uint32_t)f32_as_i32(__fdiv_rn(nz, (float)DH_ZSCALEFACTOR)) - (uint32_t)org[2];
+        if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], v);
+    }
 }
 
 __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
@@ -1449,41 +1468,40 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
             __syncthreads();
             if (which == 0) {
-                // Two steps per chunk of CL_LIST hit records: (1) every thread tests the vote bounding boxes of
-                // its records against the region and appends the survivors to a list (in `prod`, idle now);
-                // (2) 16 lanes share each surviving record and take its offset votes 16 apart, so the chain
-                // of dependent vote loads per lane is n_votes / 16 long instead of n_votes.
+                // Two steps: (1) every thread tests the vote bounding boxes of its records against the region and
+                // appends the survivors to a list (in `prod`, idle now; a record that finds the list full is
+                // handled by its thread alone); (2) 16 lanes share each listed record and take its offset votes
+                // 16 apart, so the chain of dependent vote loads per lane is n_votes / 16 long instead of n_votes.
                 uint32_t *list = (uint32_t *)prod;
-                for (uint32_t c0 = 0; c0 < n_hits; c0 += CL_LIST) {
-                    if (tid == 0) s_total = 0;
-                    __syncthreads();
-                    const uint32_t c1 = min(n_hits, c0 + CL_LIST);
-                    for (uint32_t i = c0 + tid; i < c1; i += CL_THREADS) {
-                        const int4 b0 = ((const int4 *)(box + i))[0], b1 = ((const int4 *)(box + i))[1];
-                        const uint32_t fc = (uint32_t)b1.w;
-                        if ((fc & LF_OFF) && range_hits_span(b0.x, b0.w, org[0], RG) && range_hits_span(b0.y, b1.x, org[1], RG) &&
-                            range_hits_span(b0.z, b1.y, org[2], RG))
-                            list[atomicAdd(&s_total, 1u)] = i;
+                if (tid == 0) s_total = 0;
+                __syncthreads();
+                for (uint32_t i0 = 0; i0 < n_hits; i0 += CL_THREADS * 2) {        // (uniform trip count: the ballots need every lane)
+                    int4 b0[2], b1[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {                                   // two records' boxes in flight (64-VGPR budget)
+                        const uint32_t i = min(i0 + j * CL_THREADS + tid, n_hits - 1);
+                        b0[j] = ((const int4 *)(box + i))[0]; b1[j] = ((const int4 *)(box + i))[1];
                     }
-                    __syncthreads();
-                    const uint32_t np = s_total;
-                    for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) {
-                        const uint32_t i = list[k >> 4], sub = k & 15u;
-                        const float4 rec = *(const float4 *)(hits + i);
-                        const uint32_t v = box[i].v, fc = box[i].fc;
-                        const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
-                        for (uint32_t o = ob + sub; o < oe; o += 16u) {
-                            const float *of = a.f.offsets + (size_t)o * 3;
-                            float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // prediction.rs:647
-                            if (nz < 0.0f) continue;                                                                      // :650
-                            uint32_t dx = (uint32_t)f32_as_i32(nx) - (uint32_t)org[0];                                     // :667
-                            uint32_t dy = (uint32_t)f32_as_i32(ny) - (uint32_t)org[1];
-                            uint32_t dz = (uint32_t)f32_as_i32(__fdiv_rn(nz, (float)DH_ZSCALEFACTOR)) - (uint32_t)org[2];
-                            if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], v);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t i = i0 + j * CL_THREADS + tid, fc = (uint32_t)b1[j].w;
+                        const bool keep = i < n_hits && (fc & LF_OFF) && range_hits_span(b0[j].x, b0[j].w, org[0], RG) &&
+                                          range_hits_span(b0[j].y, b1[j].x, org[1], RG) && range_hits_span(b0[j].z, b1[j].y, org[2], RG);
+                        const unsigned long long bal = __ballot(keep);             // one LDS atomic per wave, ranks from the ballot
+                        uint32_t wb = 0;
+                        if (lane == 0 && bal) wb = atomicAdd(&s_total, (uint32_t)__popcll(bal));
+                        wb = __shfl(wb, 0);
+                        if (keep) {
+                            const uint32_t slot = wb + (uint32_t)__popcll(bal & lanemask_lt());
+                            if (slot < CL_LIST) list[slot] = i;
+                            else cluster_add_votes(a, region, hits, box, i, 0u, 1u, org);   // list full: this thread takes the record alone
                         }
                     }
-                    __syncthreads();
                 }
+                __syncthreads();
+                const uint32_t np = min(s_total, (uint32_t)CL_LIST);
+                for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) cluster_add_votes(a, region, hits, box, list[k >> 4], k & 15u, 16u, org);
+                __syncthreads();
             } else if (a.leaf_hits) {
                 // Rotation votes depend only on the leaf (prediction.rs:601-636): the accumulator is
                 // sum over leaves of (times the leaf voted) x (its distinct cells), so the gather walks
@@ -1495,15 +1513,21 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                     if (tid == 0) s_total = 0;
                     __syncthreads();
                     const uint32_t c1 = min(a.f.n_leaves, c0 + CL_LIST);
-                    for (uint32_t l = c0 + tid; l < c1; l += CL_THREADS) {
-                        if (!lh[l]) continue;
-                        const uint4 t2 = ((const uint4 *)(a.f.tpl + l))[2];
-                        const uint32_t bl = t2.y, bh = t2.z;
-                        if (bl == 0xFFFFFFFFu) continue;
-                        if (range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG) &&
-                            range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG) &&
-                            range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG))
-                            list[atomicAdd(&s_total, 1u)] = l;
+                    for (uint32_t l0 = c0; l0 < c1; l0 += CL_THREADS) {          // (uniform trip count: the ballot needs every lane)
+                        const uint32_t l = l0 + tid;
+                        bool keep = false;
+                        if (l < c1 && lh[l]) {
+                            const uint4 t2 = ((const uint4 *)(a.f.tpl + l))[2];
+                            const uint32_t bl = t2.y, bh = t2.z;
+                            keep = bl != 0xFFFFFFFFu && range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG) &&
+                                   range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG) &&
+                                   range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG);
+                        }
+                        const unsigned long long bal = __ballot(keep);             // one LDS atomic per wave, ranks from the ballot
+                        uint32_t wb = 0;
+                        if (lane == 0 && bal) wb = atomicAdd(&s_total, (uint32_t)__popcll(bal));
+                        wb = __shfl(wb, 0);
+                        if (keep) list[wb + (uint32_t)__popcll(bal & lanemask_lt())] = l;
                     }
                     __syncthreads();
                     const uint32_t np = s_total;
