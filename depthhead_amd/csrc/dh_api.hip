@@ -680,6 +680,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
             ea.hit_count = hit_count; ea.hits_cap = p->hits_cap;
             ea.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
             ea.dbg_flags = ta.dbg_flags;
+            if (const char *e = getenv("DH_EMIT_STOP")) ea.stop = atoi(e);
             HIP_TRY(dh_launch_emit(ea, s));
         }
     } else if (profile) HIP_TRY(hipEventRecord(p->ev[5], s));

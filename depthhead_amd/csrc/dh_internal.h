@@ -128,6 +128,7 @@ struct EmitArgs {
     uint32_t  hits_cap;     // records per frame
     uint32_t *leaf_hits;    // nullable [n_frames][n_leaves]: how often each leaf cast rotation votes (zeroed per batch)
     uint8_t  *dbg_flags;    // nullable [n][npatch]: bit 1 set for windows that pass the gate
+    int stop;               // profiling knob (env DH_EMIT_STOP): 1 / 2 = return after the window lookup / after the gate
 };
 
 // k_boxsum: per frame the image of all rw x rh rectangle sums, out[y][x] = sum of the rectangle whose

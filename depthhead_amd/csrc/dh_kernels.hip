@@ -1058,7 +1058,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
         if (__ballot(tile < 0) == 0ull) break;
     }
     const bool live = tile >= 0;
-    if (__ballot(live) == 0ull) return;
+    if (__ballot(live) == 0ull || a.stop == 1) return;
     if (!live) { tile = 0; slot = 0; }
     const int T = (int)a.f.n_trees;
     const size_t w = (size_t)tile * pp + slot;                           // slot in the frame's window list
@@ -1099,6 +1099,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
         if (!gated) { cnt = 0; voting = 0; }
         if (gated && a.dbg_flags) a.dbg_flags[(size_t)frame * a.npatch + gp] = 3;
     }
+    if (a.stop == 2) return;
     // slots in the frame's hit arrays: one atomic per wave, exclusive prefix of the lanes' counts
     const uint32_t incl = wave_incl_scan(cnt);
     const uint32_t wave_total = __shfl(incl, WAVE - 1);
