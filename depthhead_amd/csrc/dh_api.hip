@@ -694,6 +694,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         va.hit_count = hit_count; va.hits_cap = p->hits_cap;
         va.pos_grid = pos_grid; va.rot_grid = rot_grid;
         va.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
+        if (const char *e = getenv("DH_VOTE_STOP")) va.stop = atoi(e);
         HIP_TRY(dh_launch_vote(va, s));
     }
     if (profile) HIP_TRY(hipEventRecord(p->ev[2], s));

@@ -1244,6 +1244,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         for (int i = tid; i < a.h; i += VOTE_THREADS) gyt[i] = (uint8_t)((uint32_t)i * DH_GRID / (uint32_t)a.h);
     }
     __syncthreads();
+    if (a.stop == 1) return;
     const HitRec *hits = a.hits + (size_t)frame * a.hits_cap;
     const HitBox *box = a.hit_box + (size_t)frame * a.hits_cap;
     const HitRot *hr = a.hit_rot + (size_t)frame * a.hits_cap;
@@ -1294,6 +1295,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
             if (acc) atomicAdd(&pos[last], acc);
         }
     }
+    if (a.stop == 2) return;
     if (a.leaf_hits) {
         // Rotation votes depend only on the leaf (prediction.rs:601-636): with the per-frame leaf histogram the
         // 20^3 guess grid is the sum over the leaves that voted of count x v x (their distinct cells); u32
@@ -1310,6 +1312,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         }
     }
     __syncthreads();
+    if (a.stop == 3) return;
     uint32_t *gp = a.pos_grid + (size_t)frame * DH_POSGRID, *gr = a.rot_grid + (size_t)frame * DH_GRID3;
     for (int i = tid; i < DH_POSGRID; i += VOTE_THREADS) if (pos[i]) atomicAdd(&gp[i], pos[i]);
     for (int i = tid; i < DH_GRID3; i += VOTE_THREADS) if (rot[i]) atomicAdd(&gr[i], rot[i]);
