@@ -239,15 +239,18 @@ hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int
 }
 
 // ================================================================== k_traverse
-// One 1024-thread workgroup per tile of PX x PY sliding-window positions of one frame.
+// One 1024-thread workgroup per tile of PX x PY sliding-window positions of one frame: build the
+// tile's image in LDS, gate out background windows, walk every tree for the active windows, write
+// the leaves to the frame's window list (k_emit turns them into hit records).
 //
-// LDS: [ SAT (fh+1) x ss u32 | leaf ids npt*T i32 | p3 npt*3 f32 | active list npt u32 | misc ]
+// LDS: [ region / SAT | active windows npt u32 | their grid positions npt u32 | misc ]
 //
-// The summed-area table is kept modulo 2^32: any rectangle inside a patch sums to
-// < sw*sh*65535 < 2^32 (checked at predictor creation), so differences are exact and one rect
-// mean costs 4 LDS reads instead of the reference's O(area) pixel loop (types.rs:317-339).
-// UNI = true: all split rectangles share one size; after the background gate the SAT is converted
-// in place into the image of rw x rh box sums, so a node costs 2 LDS reads and an integer compare.
+// UNI = true (every split rectangle has one size): the image is the tile's region of the frame's
+// rectangle-sum image (k_boxsum), copied straight into LDS; a node costs 2 LDS reads and an integer
+// compare.  UNI = false: a summed-area table of the tile's footprint modulo 2^32 is built here (any
+// rectangle inside a patch sums to < sw*sh*65535 < 2^32, checked at predictor creation, so the
+// differences are exact) and one rectangle mean costs 4 LDS reads instead of the reference's O(area)
+// pixel loop (types.rs:317-339).
 #define TRAV_THREADS 1024
 #define TRAV_WAVES (TRAV_THREADS / WAVE)
 #define ROWS_IN_FLIGHT 8
@@ -260,8 +263,8 @@ hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int
 // windows' origins: `step` columns apart along a row of windows, step * ss apart between rows.
 // With step = 4 a linear layout would use 16 of the 64 LDS banks.  The columns are therefore
 // de-interleaved by m = the largest power of two dividing step (at most 8): cell (y, x) lives at
-// y * ss + (x mod m) * q + x / m with q = ceil(bw / m) rounded up to a multiple of 4.  Window origins are multiples of m, so the
-// slot of (origin + rectangle offset) is still base(origin) + offset(rectangle), neighbouring
+// y * ss + (x mod m) * q + x / m with q = ceil(bw / m) rounded up to a multiple of 4.  Window origins
+// are multiples of m, so the slot of (origin + rectangle offset) is still base(origin) + offset(rectangle), neighbouring
 // windows are step / m (odd) slots apart, and the row stride ss >= m * q is padded so that the
 // rows of windows a wave spans land on different banks.
 void dh_traverse_swizzle(int px, int step, int sw, int rw, int *swz_log2, int *swz_q, int *ss_row) {
