@@ -1069,6 +1069,9 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
     bool gated = false;
     const int32_t *wl = a.win_leaf + (size_t)frame * a.win_cap * T + w;
     unsigned long long voting = 0;          // bit t: the leaf reached in tree t casts votes (T <= 64; else recomputed below)
+    uint32_t rotv = 0, l[EMIT_BATCH];       // bit k: leaf l[k] casts rotation votes and the window passed the gate
+#pragma unroll
+    for (int k = 0; k < EMIT_BATCH; ++k) l[k] = 0;
     uint16_t zc = 0;                        // depth at the window centre
     if (live) {
         gp = a.win_patch[(size_t)frame * a.win_cap + w];
@@ -1076,7 +1079,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
         // together, so a window costs two dependent round trips per batch (one batch for T <= 16).
         double prob = 0.0;
         for (int t0 = 0; t0 < T; t0 += EMIT_BATCH) {
-            uint32_t l[EMIT_BATCH], lf[EMIT_BATCH];
+            uint32_t lf[EMIT_BATCH];
             double pr[EMIT_BATCH];
             uint4 g[EMIT_BATCH];
 #pragma unroll
@@ -1094,13 +1097,36 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
             for (int k = 0; k < EMIT_BATCH; ++k)
                 if (t0 + k < T) {
                     prob = __dadd_rn(prob, pr[k]);                                   // tree order, f64 (prediction.rs:582-584)
-                    if ((lf[k] & LF_PROB) && (lf[k] & (LF_ROT | LF_OFF))) { cnt++; voting |= 1ull << ((t0 + k) & 63); }
+                    if ((lf[k] & LF_PROB) && (lf[k] & (LF_ROT | LF_OFF))) {
+                        cnt++; voting |= 1ull << ((t0 + k) & 63);
+                        if (lf[k] & LF_ROT) rotv |= 1u << k;                          // (only read when T <= EMIT_BATCH)
+                    }
                 }
         }
         prob = __ddiv_rn(prob, (double)T);
         gated = prob > DH_PROB_GATE;
-        if (!gated) { cnt = 0; voting = 0; }
+        if (!gated) { cnt = 0; voting = 0; rotv = 0; }
         if (gated && a.dbg_flags) a.dbg_flags[(size_t)frame * a.npatch + gp] = 3;
+    }
+    // Leaf histogram (rotation votes per leaf, read by k_vote and k_cluster): neighbouring windows -- adjacent
+    // lanes -- mostly reach the same leaf of a tree, so runs of equal leaves along the wave are counted with
+    // one ballot and added by the run's first lane: a few times fewer global atomics than one per hit record.
+    const bool hist_here = a.leaf_hits && T <= EMIT_BATCH;
+    if (hist_here) {
+        uint32_t *lhist = a.leaf_hits + (size_t)frame * a.f.n_leaves;
+#pragma unroll
+        for (int k = 0; k < EMIT_BATCH; ++k) {
+            if (k >= T) continue;                                                    // (uniform)
+            const bool v = (rotv >> k) & 1u;
+            const uint32_t key = v ? l[k] : 0xFFFFFFFFu;
+            const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+            const bool cont = v && lane > 0 && prev == key;                          // continues the previous lane's run
+            const unsigned long long c = __ballot(cont);
+            if (v && !cont) {
+                const unsigned long long rest = lane == WAVE - 1 ? 0ull : (c >> (lane + 1));
+                atomicAdd(&lhist[key], 1u + (uint32_t)__builtin_ctzll(~rest));      // run length = 1 + following continuations
+            }
+        }
     }
     if (a.stop == 2) return;
     // slots in the frame's hit arrays: one atomic per wave, exclusive prefix of the lanes' counts
@@ -1178,7 +1204,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
                                                  f32_as_i32(__fsub_rn(p2, mx2)), f32_as_i32(__fsub_rn(p0, mn0)));
             ((int4 *)(dbox + o))[1] = make_int4(f32_as_i32(__fsub_rn(p1, mn1)), f32_as_i32(__fsub_rn(p2, mn2)), (int)t1.z, (int)t1.w);
             *(uint4 *)(drot + o) = make_uint4(t2v.y, t2v.z, t2v.w, t3.x);                           // rlo, rhi, rb, n_rot
-            if (a.leaf_hits && (t1.w & LF_ROT)) atomicAdd(&a.leaf_hits[(size_t)frame * a.f.n_leaves + lid], 1u);
+            if (a.leaf_hits && !hist_here && (t1.w & LF_ROT)) atomicAdd(&a.leaf_hits[(size_t)frame * a.f.n_leaves + lid], 1u);
         }
     }
 }
