@@ -516,6 +516,26 @@ def test_randomized_differential(hp_mod, oracle):
             assert np.array_equal(poses["rotation"][i], ref.rotation), (tag, poses["rotation"][i], ref.rotation)
 
 
+def test_state_across_batches(hp_mod):
+    """One predictor, many batches of varying size and content (empty frames, half-empty frames): every pose
+    equals the pose the same frame got in a reference pass -- no per-batch state (counters, tile flags, window
+    lists, leaf histogram) leaks from one batch into the next."""
+    forest = synth.fit_forest(6, 10, synth.FOREST_SEED_BASE + 5, w=320, h=240, n_frames=24)
+    model = synth.ModelParams(stepwidth=4)
+    frames = synth.biwi_batch(24, 320, 240, first=40)
+    frames[3] = 0
+    frames[7, :, :160] = 0
+    intr = hp_mod.IntrinsicMatrix(synth.default_intrinsic(320, 240))
+    rs = np.random.RandomState(11)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        ref = hp.predict_batch(frames, intr).copy()
+        for it in range(25):
+            idx = rs.randint(0, 24, int(rs.randint(1, 25)))
+            out = hp.predict_batch(frames[idx].copy(), intr)
+            assert np.array_equal(out["mid_point"], ref["mid_point"][idx]), f"batch {it}"
+            assert np.array_equal(out["rotation"], ref["rotation"][idx]), f"batch {it}"
+
+
 def test_fewer_hits_than_vote_slices(hp_mod, oracle):
     """Frames with 1..6 hit records (one or two windows, three single-split trees whose leaves all
     vote): most of k_vote's 8 slices get no record but still own their share of the leaf histogram
