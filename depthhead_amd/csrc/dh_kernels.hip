@@ -689,7 +689,10 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
                 acc |= (r.x - pe.x) | (r.y - pe.y) | (r.z - pe.z) | (r.w - pe.w);
                 uint32_t *orow = out + (size_t)(Y0 + t - warm) * row_pitch;
                 if (a.lg == 0) *(uint4 *)(orow + o0) = make_uint4(r.x - pe.x, r.y - pe.y, r.z - pe.z, r.w - pe.w);
-                else { orow[o0] = r.x - pe.x; orow[o1] = r.y - pe.y; orow[o2] = r.z - pe.z; orow[o3] = r.w - pe.w; }
+                else if (a.lg == 1) {                      // two planes: columns x, x + 2 and x + 1, x + 3 are neighbours in theirs
+                    *(uint2 *)(orow + o0) = make_uint2(r.x - pe.x, r.z - pe.z);
+                    *(uint2 *)(orow + o1) = make_uint2(r.y - pe.y, r.w - pe.w);
+                } else { orow[o0] = r.x - pe.x; orow[o1] = r.y - pe.y; orow[o2] = r.z - pe.z; orow[o3] = r.w - pe.w; }
             }
             v0 -= l[k].x & 0xffffu; v1 -= l[k].x >> 16; v2 -= l[k].y & 0xffffu; v3 -= l[k].y >> 16;
             // Which k_traverse tiles have a non-zero rectangle sum in their region?  Every 32 output rows
