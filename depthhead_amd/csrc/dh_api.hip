@@ -493,6 +493,7 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
     }
     g.tiles_x = (g.nx + g.px - 1) / g.px;
     g.tiles_y = (g.ny + g.py - 1) / g.py;
+    if ((long)g.tiles_x * g.tiles_y > 65535) return fail(DH_ESIZE, "frame %dx%d needs %ld tiles per frame (limit 65535)", g.w, g.h, (long)g.tiles_x * g.tiles_y);
     g.win_cap = g.tiles_x * g.tiles_y * g.px * g.py;
     g.flag_words = (g.tiles_x * g.tiles_y + 3) / 4;
     g.ss_row = dh_traverse_row_stride(g.px, step, sw, rw);
