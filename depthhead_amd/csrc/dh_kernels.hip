@@ -1206,7 +1206,8 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
             ((int4 *)(dbox + o))[0] = make_int4(f32_as_i32(__fsub_rn(p0, mx0)), f32_as_i32(__fsub_rn(p1, mx1)),
                                                  f32_as_i32(__fsub_rn(p2, mx2)), f32_as_i32(__fsub_rn(p0, mn0)));
             ((int4 *)(dbox + o))[1] = make_int4(f32_as_i32(__fsub_rn(p1, mn1)), f32_as_i32(__fsub_rn(p2, mn2)), (int)t1.z, (int)t1.w);
-            *(uint4 *)(drot + o) = make_uint4(t2v.y, t2v.z, t2v.w, t3.x);                           // rlo, rhi, rb, n_rot
+            // the rotation record is only read when there is no leaf histogram (k_vote, k_cluster) or by the vote-dump tap
+            if (!a.leaf_hits || a.dbg_flags) *(uint4 *)(drot + o) = make_uint4(t2v.y, t2v.z, t2v.w, t3.x);    // rlo, rhi, rb, n_rot
             if (a.leaf_hits && !hist_here && (t1.w & LF_ROT)) atomicAdd(&a.leaf_hits[(size_t)frame * a.f.n_leaves + lid], 1u);
         }
     }
