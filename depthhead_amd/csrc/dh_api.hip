@@ -398,6 +398,18 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     STEP(upload(p, &d.off_begin, f->off_begin));
     STEP(upload(p, &d.rot_begin, f->rot_begin));
     STEP(upload(p, &d.offsets, f->offsets));
+    if (rc == DH_OK) {
+        // the offset votes once more as (x, y, z, 0) records, every leaf's run on a 64-byte boundary: the kernels
+        // that walk a leaf's votes (k_vote, k_cluster) then touch whole cache lines with one 16-byte load per lane
+        std::vector<uint32_t> b4(p->n_leaves + 1, 0);
+        for (uint32_t L = 0; L < p->n_leaves; ++L) b4[L + 1] = b4[L] + ((f->off_begin[L + 1] - f->off_begin[L] + 3u) & ~3u);
+        std::vector<float4> o4((size_t)b4[p->n_leaves] + 4, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (uint32_t L = 0; L < p->n_leaves; ++L)
+            for (uint32_t k = f->off_begin[L]; k < f->off_begin[L + 1]; ++k)
+                o4[b4[L] + (k - f->off_begin[L])] = make_float4(f->offsets[(size_t)k * 3], f->offsets[(size_t)k * 3 + 1], f->offsets[(size_t)k * 3 + 2], 0.f);
+        STEP(upload(p, &d.off4, o4));
+        STEP(upload(p, &d.off4_begin, b4));
+    }
     STEP(upload(p, &d.rotations, f->rotations));
     STEP(dev_alloc(p, &d.leaf_v, p->n_leaves, true));
     STEP(dev_alloc(p, &d.leaf_flags, p->n_leaves, true));

@@ -37,6 +37,8 @@ struct DevForest {
     const uint32_t *off_begin;
     const uint32_t *rot_begin;
     const float    *offsets;
+    const float4   *off4;        // the same votes as 16-byte records (x, y, z, 0), every leaf's run starting on a 64-byte line:
+    const uint32_t *off4_begin;  // per leaf, index of its first record in off4 (a multiple of 4); hit records carry this index
     const double   *rotations;
     uint32_t n_trees, n_nodes, n_leaves, n_off, n_rot;
     // prepared

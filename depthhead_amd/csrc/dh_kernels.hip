@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) k_leaf_prepare(DevForest f) {
     f.rbin_box_hi[L] = bmax[0] | (bmax[1] << 8) | (bmax[2] << 16);
     LeafTpl t;
     for (int k = 0; k < 3; ++k) { t.omin[k] = omin[k]; t.omax[k] = omax[k]; }
-    t.v = v; t.fc = flags | (n_off << 8); t.ob = ob;
+    t.v = v; t.fc = flags | (n_off << 8); t.ob = f.off4_begin[L];     // hit records index the padded 16-byte votes
     t.rlo = (flags & LF_ROT) ? f.rbin_box[L] : 0xFFFFFFFFu; t.rhi = f.rbin_box_hi[L];
     t.rb = rb; t.n_rot = n_fine | (n_rough << 16); t.flags = t.fc & 0xffu; t.prob = prob;
     f.tpl[L] = t;
@@ -1300,8 +1300,8 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
 #pragma unroll
                 for (int j = 0; j < VOTE_ILP; ++j) {
                     const uint32_t o = min(o0 + VOTE_SUB * j, oe - 1);
-                    const float *of = a.f.offsets + (size_t)o * 3;
-                    ox[j] = of[0]; oy[j] = of[1]; oz[j] = of[2];
+                    const float4 of = a.f.off4[o];                          // 4 lanes x 16 B = one 64-byte line per record group
+                    ox[j] = of.x; oy[j] = of.y; oz[j] = of.z;
                 }
 #pragma unroll
                 for (int j = 0; j < VOTE_ILP; ++j) {
@@ -1395,8 +1395,8 @@ __device__ __forceinline__ void cluster_add_votes(const ClusterArgs &a, uint32_t
     const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
 #pragma unroll 1
     for (uint32_t o = ob + sub; o < oe; o += nsub) {
-        const float *of = a.f.offsets + (size_t)o * 3;
-        float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]); // prediction.rs:647
+        const float4 of = a.f.off4[o];
+        float nx = __fsub_rn(rec.x, of.x), ny = __fsub_rn(rec.y, of.y), nz = __fsub_rn(rec.z, of.z); // prediction.rs:647
         if (nz < 0.0f) continue;                                                                      // :650
         uint32_t dx = (uint32_t)f32_as_i32(nx) - (uint32_t)org[0];                                     // :667
         uint32_t dy = (uint32_t)f32_as_i32(ny) - (uint32_t)org[1];
@@ -1728,8 +1728,8 @@ __global__ void __launch_bounds__(256) k_votes_dump(VotesDumpArgs a) {
         if (a.which == 0 && (fc & LF_OFF)) {
             const uint32_t ob = __float_as_uint(rec.w);
             for (uint32_t o = ob; o < ob + (fc >> 8); ++o) {
-                const float *of = a.f.offsets + (size_t)o * 3;
-                float nx = __fsub_rn(rec.x, of[0]), ny = __fsub_rn(rec.y, of[1]), nz = __fsub_rn(rec.z, of[2]);
+                const float4 of = a.f.off4[o];
+                float nx = __fsub_rn(rec.x, of.x), ny = __fsub_rn(rec.y, of.y), nz = __fsub_rn(rec.z, of.z);
                 if (nz < 0.0f) continue;
                 uint32_t k = atomicAdd(a.count, 1u);
                 if (k < a.cap) {
