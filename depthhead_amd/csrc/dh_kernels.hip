@@ -1648,13 +1648,21 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                 uint64_t b = __ballot(fv != 0);
                 if (fv) {
                     uint32_t k = cnt[c * CL_WAVES + wave] + (uint32_t)__popcll(b & lanemask_lt());
-                    if (k >= base && k < base + CL_PROD_CAP) {
-                        float w = __fmul_rn(a.kern_ord[cell], (float)fv);                   // meanshift.rs:370-379
-                        float ax = (float)(int32_t)((uint32_t)pos[0] + dx - 10u);           // :373-375
-                        float ay = (float)(int32_t)((uint32_t)pos[1] + dy - 10u);
-                        float az = (float)(int32_t)((uint32_t)pos[2] + dz - 10u);
-                        *(float4 *)(prod + (k - base) * 4) = make_float4(__fmul_rn(ax, w), __fmul_rn(ay, w), __fmul_rn(az, w), w);
-                    }
+                    // this sweep only parks (cell, value) in the cell's slot: no global load sits inside it
+                    if (k >= base && k < base + CL_PROD_CAP) *(uint2 *)(prod + (k - base) * 4) = make_uint2(cell, fv);
+                }
+            }
+            __syncthreads();
+            {   // one thread per parked cell: Gaussian weight (one global load, all in flight together) and products, in place
+                const uint32_t m = min((uint32_t)CL_PROD_CAP, total - base);
+                if ((uint32_t)tid < m) {
+                    const uint2 cf = *(const uint2 *)(prod + tid * 4);
+                    const uint32_t cell = cf.x, dz = cell % 20u, dy = (cell / 20u) % 20u, dx = cell / 400u;
+                    float w = __fmul_rn(a.kern_ord[cell], (float)cf.y);                     // meanshift.rs:370-379
+                    float ax = (float)(int32_t)((uint32_t)pos[0] + dx - 10u);               // :373-375
+                    float ay = (float)(int32_t)((uint32_t)pos[1] + dy - 10u);
+                    float az = (float)(int32_t)((uint32_t)pos[2] + dz - 10u);
+                    *(float4 *)(prod + tid * 4) = make_float4(__fmul_rn(ax, w), __fmul_rn(ay, w), __fmul_rn(az, w), w);
                 }
             }
             __syncthreads();
