@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // (prediction.rs:567-576) and leaves before building anything
     bool nonzero = a.tile_flags[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] != 0;
     if (tid < 8) misc[tid] = 0;
-    __syncthreads();
+    if (!UNI) __syncthreads();        // (the uniform path's copy ends with a barrier before misc is used)
     if (UNI && nonzero) {
         // The frame's box-sum image is stored with the same column de-interleave as the LDS region
         // (row = m planes of box_plane words; plane c holds the columns = c mod m), so a region row is
