@@ -1,0 +1,64 @@
+"""Extended randomized differential run (GPU box): like tests/test_gpu_parity.py::test_randomized_differential but
+with many more seeded configurations, biased towards multi-tile frames and uniform forests.  Usage:
+    python tools/fuzz_parity.py [first_case] [n_cases]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from depthhead_amd import synth
+from depthhead_amd.prediction import HoughPrediction, IntrinsicMatrix
+from oracle import pyoracle
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+big = len(sys.argv) > 3 and sys.argv[3] == "big"      # larger frames, up to 70 trees
+bad = 0
+refused = 0
+frames_done = 0
+hits_total = 0
+t0 = time.time()
+for case in range(first, first + count):
+    rs = np.random.RandomState(777000 + case)
+    sw, sh = int(rs.randint(16, 97)), int(rs.randint(16, 97))
+    w, h = sw + int(rs.randint(1, 420)), sh + int(rs.randint(1, 300))
+    if big:
+        w, h = sw + int(rs.randint(300, 900)), sh + int(rs.randint(200, 640))
+    step = int(rs.choice([1, 2, 3, 4, 4, 4, 5, 6, 8, 10, 12]))
+    trees, depth = int(rs.randint(1, 18)), int(rs.randint(1, 12))
+    if big and rs.rand() < 0.3:
+        trees = int(rs.randint(18, 71))
+    mixed = rs.rand() < 0.2
+    forest = synth.synth_forest(trees, depth, 9000 + case, patch=(sw, sh), rect_scale=float(rs.uniform(0.1, 0.6)),
+                                rect_scale_max=float(rs.uniform(0.6, 0.9)) if mixed else None,
+                                full_depth=int(rs.randint(0, depth + 1)), p_split=float(rs.uniform(0.4, 0.95)))
+    model = synth.ModelParams(stepwidth=step, subimage_width=sw, subimage_height=sh,
+                              gaussian_sigma=float(rs.uniform(0.5, 30.0)), meanshift_iterations=int(rs.randint(0, 25)))
+    n = int(rs.randint(1, 4))
+    frames = np.stack([synth.biwi_like(max(w, 96), max(h, 96), 19000 + case * 7 + i)[:h, :w] for i in range(n)]).copy()
+    if big:
+        frames = np.tile(frames, (1, 1, 1))
+    if rs.rand() < 0.25:
+        frames[0] = (rs.rand(h, w) < 0.01) * rs.randint(1, 65536, (h, w))
+    if rs.rand() < 0.25:
+        frames[-1, :, : w // 2] = 0
+    f = float(rs.uniform(200, 900))
+    K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], dtype=np.float32)
+    try:
+        with HoughPrediction(forest, model, device=0) as hp:
+            hp.debug_enable(True)
+            poses = hp.predict_batch(frames.astype(np.uint16), IntrinsicMatrix(K))
+            leaf = hp.debug_leaf_indices(n, w, h)
+            pg, rg = hp.debug_grids(n)
+            hits_total += int(hp.debug_hit_counts(n).sum())
+    except Exception as e:   # geometry refused (e.g. patch too large): fine as long as it is a clean error
+        refused += 1
+        print("case", case, "refused:", str(e)[:80])
+        continue
+    for i in range(n):
+        frames_done += 1
+        ref = pyoracle.predict(forest, model, frames[i], K)
+        ok = (np.array_equal(leaf[i], ref.leaf_idx) and np.array_equal(pg[i], ref.pos_grid) and np.array_equal(rg[i], ref.rot_grid)
+              and np.array_equal(poses["mid_point"][i], ref.mid_point) and np.array_equal(poses["rotation"][i], ref.rotation))
+        if not ok:
+            bad += 1
+            print(f"MISMATCH case {case} frame {i}: {w}x{h} patch {sw}x{sh} step {step} trees {trees} depth {depth} mixed {mixed}")
+print(f"{count} cases from {first}: {frames_done} frames compared, {refused} cases refused, {hits_total} hit records in total, {bad} mismatching frames, {time.time() - t0:.0f} s")
