@@ -567,7 +567,9 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
         if (rc == DH_OK && hipMemset(p->box, 0, words * sizeof(uint32_t)) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box)");   // the slack columns stay 0
     }
     // one block, one memset per batch: hit counters | guess grids | tile flags | window counts | leaf histogram
-    const bool leaf_hist = p->n_leaves <= DH_LEAF_HIST_MAX && !getenv("DH_NO_LEAF_HIST");
+    uint32_t hist_max = DH_LEAF_HIST_MAX;
+    if (const char *e = getenv("DH_LEAF_HIST_MAX")) hist_max = (uint32_t)std::max(0, atoi(e));
+    const bool leaf_hist = p->n_leaves <= hist_max && !getenv("DH_NO_LEAF_HIST");
     const size_t counter_words = (size_t)cap * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words + (size_t)g.tiles_x * g.tiles_y);
     STEP(dev_alloc(p, &p->counters, counter_words + (leaf_hist ? (size_t)cap * p->n_leaves : 0)));
     if (rc == DH_OK) p->leaf_hits = leaf_hist ? p->counters + counter_words : nullptr;
