@@ -139,3 +139,24 @@ def test_product_code_never_touches_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, fn), errors="replace").read()
                 assert "pyoracle" not in txt and "dh_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+
+
+def test_cpp_example_compiles_and_links(tmp_path):
+    """examples/predict_frame.cpp -- a host with no Python in it -- builds against the header and links the
+    shared library (it needs a GPU to run: tests/test_gpu_parity.py::test_cpp_example_runs)."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "depthhead_amd")
+    if not os.path.exists(os.path.join(libdir, "libdepthhead_hip.so")):
+        from depthhead_amd import build
+        build.build()
+    exe = str(tmp_path / "predict_frame")
+    cmd = [gxx, "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "predict_frame.cpp"),
+           "-L" + libdir, "-ldepthhead_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert os.path.exists(exe)

@@ -658,3 +658,22 @@ def test_error_behaviour_on_device(hp_mod, hip_lib):
     with pytest.raises(DepthheadError) as ei:
         hp_mod.HoughPrediction(wide, synth.ModelParams())       # 80x80 patch
     assert ei.value.code == -2 and "leaves the" in str(ei.value)
+
+
+def test_cpp_example_runs(hp_mod, tmp_path):
+    """The pure C++ host of examples/predict_frame.cpp (no Python, no PyTorch in the process) builds, runs on the
+    GPU and prints a pose for its synthetic head at 900 mm."""
+    import os, re, shutil, subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "depthhead_amd")
+    exe = str(tmp_path / "predict_frame")
+    subprocess.run([gxx, "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "predict_frame.cpp"),
+                    "-L" + libdir, "-ldepthhead_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    m = re.search(r"mid_point = \((-?\d+), (-?\d+), (-?\d+)\) mm", res.stdout)
+    assert m, res.stdout
+    assert 700 <= int(m.group(3)) <= 1100, res.stdout          # the blob's surface is at 805..900 mm; votes point 20..24 mm behind it
