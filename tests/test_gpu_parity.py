@@ -316,6 +316,32 @@ def test_device_resident_api_with_torch_stream(hp_mod, oracle):
     assert np.array_equal(poses["mid_point"], ref["mid_point"]) and np.array_equal(poses["rotation"], ref["rotation"])
 
 
+@pytest.mark.parametrize("general", [False, True])
+def test_device_frames_at_a_two_byte_aligned_address(hp_mod, oracle, general):
+    """Device-resident frames that start on an odd 2-byte boundary (a slice of a larger buffer): the kernels'
+    8-byte row loads must fall back to narrow loads."""
+    torch = pytest.importorskip("torch")
+    forest = synth.synth_forest(5, 9, synth.FOREST_SEED_BASE + 8)
+    model = synth.ModelParams(stepwidth=4)
+    w, h, n = 320, 240, 3
+    frames = synth.biwi_batch(n, w, h, first=60)
+    K = synth.default_intrinsic(w, h)
+    dev = torch.device("cuda:0")
+    from depthhead_amd._lib import POSE_DTYPE
+    with general_path(general):
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            base = torch.zeros(n * w * h + 1, dtype=torch.int16, device=dev)
+            base[1:] = torch.from_numpy(frames.view(np.int16).reshape(-1)).to(dev)
+            fr = base[1:]
+            assert fr.data_ptr() % 4 == 2
+            out = torch.zeros(n * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            hp.predict_batch_device(fr.data_ptr(), n, w, h, hp_mod.IntrinsicMatrix(K), out.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
+            torch.cuda.synchronize(dev)
+            poses = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)
+    ref = oracle.predict_batch(forest, model, frames, K)
+    assert np.array_equal(poses["mid_point"], ref["mid_point"]) and np.array_equal(poses["rotation"], ref["rotation"])
+
+
 def test_golden_fixtures_without_oracle(hp_mod):
     """HIP path against the committed fixtures (tests/golden/*.npz) -- no oracle involved."""
     import golden_util
