@@ -882,7 +882,10 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             const int c = (lane * (65536 / q4 + 1)) >> 16, g = lane - c * q4;      // piece -> (plane, group); exact for lane < 64
             const uint32_t *src = bx + (size_t)c * a.box_plane + 4 * g;
             const size_t row_pitch = (size_t)a.box_plane << a.swz_log2;
-            if (lane < pieces)
+            // a tile cut off by the frame's edge copies only the groups that hold its own columns (the planes keep
+            // their stride q in LDS): the image has just 4 words of slack behind its last column
+            const int q4_tile = (((bw + m - 1) >> a.swz_log2) + 3) >> 2;
+            if (lane < pieces && g < q4_tile)
                 for (int y = tid >> 6; y < bh; y += TRAV_WAVES)
                     __builtin_amdgcn_global_load_lds(src + (size_t)y * row_pitch, sat + y * ss, 16, 0, 0);
         } else {
@@ -901,8 +904,10 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     }
     if (!UNI && nonzero) {
         const int strip = (fh + TRAV_WAVES - 1) / TRAV_WAVES;
-        if (fw <= 2 * WAVE && strip <= 8) nonzero = sat_rows_dpp<2>(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
-        else if (fw <= 4 * WAVE && strip <= 4) nonzero = sat_rows_dpp<4>(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
+        // (the register-scan build parks 16 strip bottoms of 64 * PPL words in the SAT area before the SAT is written:
+        // tiny footprints whose SAT is smaller than that take the pass-based build)
+        if (fw <= 2 * WAVE && strip <= 8 && a.ss_max >= TRAV_WAVES * WAVE * 2) nonzero = sat_rows_dpp<2>(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
+        else if (fw <= 4 * WAVE && strip <= 4 && a.ss_max >= TRAV_WAVES * WAVE * 4) nonzero = sat_rows_dpp<4>(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
         else nonzero = sat_passes(sat, &misc[4], img, a.w, fx0, fy0, fw, fh, ss);
     }
     if (!nonzero) {

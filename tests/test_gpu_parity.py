@@ -703,3 +703,13 @@ def test_cpp_example_runs(hp_mod, tmp_path):
     m = re.search(r"mid_point = \((-?\d+), (-?\d+), (-?\d+)\) mm", res.stdout)
     assert m, res.stdout
     assert 700 <= int(m.group(3)) <= 1100, res.stdout          # the blob's surface is at 805..900 mm; votes point 20..24 mm behind it
+
+
+@pytest.mark.parametrize("w,h,sw,sh,step", [(27, 50, 19, 49, 6), (40, 33, 24, 24, 3), (90, 30, 30, 17, 5)])
+def test_tiny_frames_general_path(hp_mod, oracle, w, h, sw, sh, step):
+    """Footprints whose summed-area table is smaller than the scratch of the register-scan build (found by
+    tools/fuzz_parity.py case 131819): the pass-based build must take over."""
+    forest = synth.synth_forest(8, 2, synth.FOREST_SEED_BASE + 400 + w, patch=(sw, sh), rect_scale=0.3, rect_scale_max=0.8)
+    model = synth.ModelParams(stepwidth=step, subimage_width=sw, subimage_height=sh)
+    frames = np.stack([synth.biwi_like(96, 96, 5200 + i)[20:20 + h, 30:30 + w] for i in range(3)]).copy()
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), full=False)

@@ -17,6 +17,8 @@ frames_done = 0
 hits_total = 0
 t0 = time.time()
 for case in range(first, first + count):
+    if (case - first) % 1000 == 0:
+        print(f"... case {case}, {bad} mismatching frames so far, {time.time() - t0:.0f} s", flush=True)
     rs = np.random.RandomState(777000 + case)
     sw, sh = int(rs.randint(16, 97)), int(rs.randint(16, 97))
     w, h = sw + int(rs.randint(1, 420)), sh + int(rs.randint(1, 300))
@@ -42,6 +44,9 @@ for case in range(first, first + count):
         frames[-1, :, : w // 2] = 0
     f = float(rs.uniform(200, 900))
     K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], dtype=np.float32)
+    if os.environ.get("FUZZ_TRACE"):
+        with open(os.environ["FUZZ_TRACE"], "a") as tf:
+            tf.write(f"case {case}: {w}x{h} patch {sw}x{sh} step {step} trees {trees} depth {depth} mixed {mixed} n {n} rect {forest.nodes['r1'][0] if forest.n_nodes else None}\n")
     try:
         with HoughPrediction(forest, model, device=0) as hp:
             hp.debug_enable(True)
@@ -60,5 +65,10 @@ for case in range(first, first + count):
               and np.array_equal(poses["mid_point"][i], ref.mid_point) and np.array_equal(poses["rotation"][i], ref.rotation))
         if not ok:
             bad += 1
+            what = [nm for nm, eq in (("leaf", np.array_equal(leaf[i], ref.leaf_idx)), ("pos_grid", np.array_equal(pg[i], ref.pos_grid)),
+                                      ("rot_grid", np.array_equal(rg[i], ref.rot_grid)), ("mid", np.array_equal(poses["mid_point"][i], ref.mid_point)),
+                                      ("rot", np.array_equal(poses["rotation"][i], ref.rotation))) if not eq]
+            print("   differs in:", what, "| leaf diffs:", int((leaf[i] != ref.leaf_idx).sum()), "| gpu pose", poses["mid_point"][i], poses["rotation"][i],
+                  "| ref", ref.mid_point, ref.rotation)
             print(f"MISMATCH case {case} frame {i}: {w}x{h} patch {sw}x{sh} step {step} trees {trees} depth {depth} mixed {mixed}")
 print(f"{count} cases from {first}: {frames_done} frames compared, {refused} cases refused, {hits_total} hit records in total, {bad} mismatching frames, {time.time() - t0:.0f} s")
