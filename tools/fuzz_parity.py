@@ -11,6 +11,7 @@ from oracle import pyoracle
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 big = len(sys.argv) > 3 and sys.argv[3] == "big"      # larger frames, up to 70 trees
+tiny = len(sys.argv) > 3 and sys.argv[3] == "tiny"    # frames barely larger than the patch, small and odd patches
 bad = 0
 refused = 0
 frames_done = 0
@@ -24,6 +25,9 @@ for case in range(first, first + count):
     w, h = sw + int(rs.randint(1, 420)), sh + int(rs.randint(1, 300))
     if big:
         w, h = sw + int(rs.randint(300, 900)), sh + int(rs.randint(200, 640))
+    if tiny:
+        sw, sh = int(rs.randint(4, 60)), int(rs.randint(4, 60))
+        w, h = sw + int(rs.randint(1, 40)), sh + int(rs.randint(1, 40))
     step = int(rs.choice([1, 2, 3, 4, 4, 4, 5, 6, 8, 10, 12]))
     trees, depth = int(rs.randint(1, 18)), int(rs.randint(1, 12))
     if big and rs.rand() < 0.3:
@@ -60,7 +64,10 @@ for case in range(first, first + count):
         continue
     for i in range(n):
         frames_done += 1
-        ref = pyoracle.predict(forest, model, frames[i], K)
+        try:
+            ref = pyoracle.predict(forest, model, frames[i], K)
+        except ValueError:                       # more distinct accumulator cells than the default tap capacity
+            ref = pyoracle.predict(forest, model, frames[i], K, cell_cap=1 << 25)
         ok = (np.array_equal(leaf[i], ref.leaf_idx) and np.array_equal(pg[i], ref.pos_grid) and np.array_equal(rg[i], ref.rot_grid)
               and np.array_equal(poses["mid_point"][i], ref.mid_point) and np.array_equal(poses["rotation"][i], ref.rotation))
         if not ok:
