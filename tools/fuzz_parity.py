@@ -12,6 +12,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 big = len(sys.argv) > 3 and sys.argv[3] == "big"      # larger frames, up to 70 trees
 tiny = len(sys.argv) > 3 and sys.argv[3] == "tiny"    # frames barely larger than the patch, small and odd patches
+api = len(sys.argv) > 3 and sys.argv[3] == "api"      # also: guesses, dense intrinsics, predict_mask, 2-D Hough votes
 bad = 0
 refused = 0
 frames_done = 0
@@ -48,28 +49,45 @@ for case in range(first, first + count):
         frames[-1, :, : w // 2] = 0
     f = float(rs.uniform(200, 900))
     K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], dtype=np.float32)
+    midp = rot = None
+    if api:
+        if rs.rand() < 0.5:
+            K = np.array([[f, rs.uniform(-2, 2), w / 2 + rs.uniform(-20, 20)], [rs.uniform(-1, 1), f * rs.uniform(0.9, 1.1), h / 2], [0, 0, 1]], dtype=np.float32)
+        if rs.rand() < 0.4:
+            midp = rs.uniform(-300, 1500, (n, 3)).astype(np.float32)
+        if rs.rand() < 0.4:
+            rot = rs.uniform(-1.5, 1.5, (n, 3))
     if os.environ.get("FUZZ_TRACE"):
         with open(os.environ["FUZZ_TRACE"], "a") as tf:
             tf.write(f"case {case}: {w}x{h} patch {sw}x{sh} step {step} trees {trees} depth {depth} mixed {mixed} n {n} rect {forest.nodes['r1'][0] if forest.n_nodes else None}\n")
     try:
         with HoughPrediction(forest, model, device=0) as hp:
             hp.debug_enable(True)
-            poses = hp.predict_batch(frames.astype(np.uint16), IntrinsicMatrix(K))
+            poses = hp.predict_batch(frames.astype(np.uint16), IntrinsicMatrix(K), midp, rot)
             leaf = hp.debug_leaf_indices(n, w, h)
             pg, rg = hp.debug_grids(n)
             hits_total += int(hp.debug_hit_counts(n).sum())
+            if api:                                   # (after the taps: these runs invalidate them)
+                masks = hp.predict_mask(frames.astype(np.uint16))
+                hough = hp.build_hough_votes(frames.astype(np.uint16), IntrinsicMatrix(K))
     except Exception as e:   # geometry refused (e.g. patch too large): fine as long as it is a clean error
         refused += 1
         print("case", case, "refused:", str(e)[:80])
         continue
     for i in range(n):
         frames_done += 1
+        mg_i = None if midp is None else midp[i]
+        rg_i = None if rot is None else rot[i]
         try:
-            ref = pyoracle.predict(forest, model, frames[i], K)
+            ref = pyoracle.predict(forest, model, frames[i], K, mg_i, rg_i)
         except ValueError:                       # more distinct accumulator cells than the default tap capacity
-            ref = pyoracle.predict(forest, model, frames[i], K, cell_cap=1 << 25)
+            ref = pyoracle.predict(forest, model, frames[i], K, mg_i, rg_i, cell_cap=1 << 25)
         ok = (np.array_equal(leaf[i], ref.leaf_idx) and np.array_equal(pg[i], ref.pos_grid) and np.array_equal(rg[i], ref.rot_grid)
               and np.array_equal(poses["mid_point"][i], ref.mid_point) and np.array_equal(poses["rotation"][i], ref.rotation))
+        if api and ok:
+            ok = np.array_equal(masks[i], pyoracle.predict_mask(forest, model, frames[i])) and np.array_equal(hough[i], pyoracle.hough_image(forest, model, frames[i], K))
+            if not ok:
+                print("   (mask / hough image differ)")
         if not ok:
             bad += 1
             what = [nm for nm, eq in (("leaf", np.array_equal(leaf[i], ref.leaf_idx)), ("pos_grid", np.array_equal(pg[i], ref.pos_grid)),
