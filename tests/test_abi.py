@@ -92,6 +92,56 @@ def test_forest_validation(hip_lib):
     assert hip_lib.dh_forest_create(None, C.byref(h)) == -1
 
 
+def test_forest_create_survives_random_corruption(hip_lib):
+    """2000 randomly corrupted forest descriptions (child links, roots, rectangles, CSR offsets, probabilities,
+    NaN / inf thresholds and votes): dh_forest_create answers every one with DH_OK or a clean DH_EFOREST /
+    DH_EINVAL -- never a crash -- and everything it accepts is structurally safe to walk."""
+    rs = np.random.RandomState(2026)
+    good = synth.synth_forest(4, 6, 11)
+    accepted = 0
+    for it in range(2000):
+        f = _clone(good)
+        for _ in range(int(rs.randint(1, 4))):
+            kind = int(rs.randint(0, 9))
+            if kind == 0:
+                f.nodes["child_zero"][rs.randint(f.n_nodes)] = int(rs.randint(-3 * f.n_leaves, 3 * f.n_nodes))
+            elif kind == 1:
+                f.nodes["child_one"][rs.randint(f.n_nodes)] = int(rs.randint(-3 * f.n_leaves, 3 * f.n_nodes))
+            elif kind == 2:
+                f.roots[rs.randint(f.n_trees)] = int(rs.randint(-2 * f.n_leaves, 2 * f.n_nodes))
+            elif kind == 3:
+                f.nodes["r1"][rs.randint(f.n_nodes)] = tuple(int(v) for v in rs.randint(0, 200, 4))
+            elif kind == 4:
+                f.nodes["r2"][rs.randint(f.n_nodes)] = tuple(int(v) for v in rs.randint(0, 65536, 4))
+            elif kind == 5:
+                f.off_begin[rs.randint(f.n_leaves)] = int(rs.randint(0, 2 * f.offsets.shape[0] + 2))     # (the last entry sizes the caller's array: left intact)
+            elif kind == 6:
+                f.rot_begin[rs.randint(f.n_leaves)] = int(rs.randint(0, 2 * f.rotations.shape[0] + 2))
+            elif kind == 7:
+                f.nodes["threshold"][rs.randint(f.n_nodes)] = rs.choice([np.nan, np.inf, -np.inf, 1e300, -1e300])
+            else:
+                f.leaf_prob[rs.randint(f.n_leaves)] = rs.choice([np.nan, -1.0, 2.0, 0.5, 0.0])
+        rc, msg = _create(hip_lib, f)
+        assert rc in (0, -1, -2), (it, rc, msg)
+        if rc == 0:
+            accepted += 1
+            # accepted forests are trees: every walk from every root terminates within n_nodes steps
+            for r in f.roots:
+                seen, stack = 0, [int(r)]
+                while stack:
+                    c = stack.pop()
+                    if c < 0:
+                        assert ~c < f.n_leaves
+                        continue
+                    assert c < f.n_nodes
+                    seen += 1
+                    assert seen <= f.n_nodes
+                    stack += [int(f.nodes["child_zero"][c]), int(f.nodes["child_one"][c])]
+        else:
+            assert msg
+    assert accepted > 0
+
+
 def test_patch_grid_matches_reference_loops(hip_lib):
     """dh_patch_grid against a literal transcription of the while loops (prediction.rs:535-548, 684-686)."""
     def loops(w, h, s, sw, sh):
