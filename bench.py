@@ -55,6 +55,7 @@ def parse():
                          "with every rank on one device (poses staged through host memory)")
     ap.add_argument("--graph", action="store_true", help="replay the batch from a captured hipGraph (launch-bound configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (other configs, PCIe-inclusive rates): profiling runs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
     return ap.parse_args()
 

@@ -47,7 +47,7 @@ EXPORTS = [
     "dh_biwi_decode_depth", "dh_biwi_parse_cal", "dh_biwi_parse_pose",
     "dh_graph_capture", "dh_graph_launch", "dh_graph_destroy",
     "dh_set_profiling", "dh_get_timing", "dh_debug_enable", "dh_debug_leaf_indices", "dh_debug_patch_flags",
-    "dh_debug_grids", "dh_debug_guesses", "dh_debug_votes", "dh_debug_meanshift", "dh_debug_hit_counts",
+    "dh_debug_grids", "dh_debug_guesses", "dh_debug_votes", "dh_debug_meanshift", "dh_debug_hit_counts", "dh_debug_geometry",
 ]
 
 
@@ -73,10 +73,11 @@ def load():
             import torch  # noqa: F401
         except ImportError:
             pass
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("DH_LIB_PATH") or LIB_PATH   # tools/ only: the -DDH_PROFILING_KNOBS twin
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the depthhead_amd product path has no CPU fallback)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name in EXPORTS:
         fn = getattr(lib, name)   # AttributeError if an export is missing
         fn.restype = C.c_int

@@ -11,6 +11,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdepthhead_hip.so")
+# profiling-only twin with the kernel-truncating DH_*_STOP / DH_TRAV_STAMPS switches compiled in (tools/pmc_phases.sh loads
+# it through DH_LIB_PATH); the product library above never contains them
+LIB_KNOBS = os.path.join(HERE, "libdepthhead_hip_knobs.so")
 SOURCES = ["dh_api.hip", "dh_kernels.hip", "dh_biwi.hip"]
 HEADERS = ["dh_internal.h", os.path.join("..", "..", "include", "depthhead_hip.h")]
 
@@ -28,23 +31,24 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def needs_build(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc(), *FLAGS, "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
+def build(force: bool = False, verbose: bool = False, knobs: bool = False) -> str:
+    lib = LIB_KNOBS if knobs else LIB
+    if not force and not needs_build(lib):
+        return lib
+    cmd = [hipcc(), *FLAGS, *(["-DDH_PROFILING_KNOBS"] if knobs else []), "-o", lib, *[os.path.join(CSRC, s) for s in SOURCES]]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, knobs="--knobs" in sys.argv))

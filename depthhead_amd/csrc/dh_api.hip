@@ -220,12 +220,55 @@ struct DeviceGuard {
 
 // ------------------------------------------------------------------ predictor
 #define DH_MAX_CHUNKS 8
-#define DH_LEAF_HIST_MAX 16384   // per-frame leaf histogram for the rotation gather (64 KB per frame at most); larger forests
+// Knobs::leaf_hist_max = 16384: per-frame leaf histogram for the rotation gather (64 KB per frame at most); larger forests
                                  // rarely hit a leaf twice per frame and walk the hit records instead (measured: 35 k leaves is a loss)
 #define DH_MIN_CHUNK_FRAMES 16
 
+// Diagnostic switches.  The environment is read ONCE, by dh_predictor_create; none of these changes
+// results (the GPU suite runs under each).  The switches that truncate kernels for per-phase
+// profiling ("results invalid") exist only in builds with -DDH_PROFILING_KNOBS (tools/), never in the
+// product library.
+struct Knobs {
+    bool force_general = false;       // DH_FORCE_GENERAL: mixed-rectangle path for any forest
+    bool no_leaf_hist = false;        // DH_NO_LEAF_HIST
+    bool box_no_ring = false;         // DH_BOX_NO_RING
+    uint32_t leaf_hist_max = 16384;   // DH_LEAF_HIST_MAX
+    int lds_budget_kb = 0;            // DH_LDS_BUDGET_KB
+    int tile_x = 0, tile_y = 0;       // DH_TILE=px,py
+    int box_band = 64;                // DH_BOX_BAND
+    int max_resident = 512;           // DH_MAX_RESIDENT_FRAMES
+    int chunks = 1;                   // DH_CHUNKS
+    int staging_depth = 2;            // DH_STAGING_DEPTH: pinned staging buffers of the host entry point (1 = serial)
+#ifdef DH_PROFILING_KNOBS
+    int trav_stop = 0, emit_stop = 0, vote_stop = 0, cl_stop = 0;
+    bool trav_stamps = false;
+#endif
+};
+
+static Knobs read_knobs() {
+    Knobs k;
+    auto geti = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    k.force_general = getenv("DH_FORCE_GENERAL") != nullptr;
+    k.no_leaf_hist = getenv("DH_NO_LEAF_HIST") != nullptr;
+    k.box_no_ring = getenv("DH_BOX_NO_RING") != nullptr;
+    k.leaf_hist_max = (uint32_t)std::max(0, geti("DH_LEAF_HIST_MAX", 16384));
+    k.lds_budget_kb = std::max(0, geti("DH_LDS_BUDGET_KB", 0));
+    if (const char *e = getenv("DH_TILE")) sscanf(e, "%d,%d", &k.tile_x, &k.tile_y);
+    k.box_band = std::max(1, geti("DH_BOX_BAND", 64));
+    k.max_resident = std::max(1, geti("DH_MAX_RESIDENT_FRAMES", 512));
+    k.chunks = std::max(1, std::min(8, geti("DH_CHUNKS", 1)));
+    k.staging_depth = std::max(1, std::min(4, geti("DH_STAGING_DEPTH", 2)));
+#ifdef DH_PROFILING_KNOBS
+    k.trav_stop = geti("DH_TRAV_STOP", 0); k.emit_stop = geti("DH_EMIT_STOP", 0);
+    k.vote_stop = geti("DH_VOTE_STOP", 0); k.cl_stop = geti("DH_CL_STOP", 0);
+    k.trav_stamps = getenv("DH_TRAV_STAMPS") != nullptr;
+#endif
+    return k;
+}
+
 struct dh_predictor {
     int device = 0;
+    Knobs knobs;
     dh_params params{};
     uint32_t n_trees = 0, n_nodes = 0, n_leaves = 0, n_off = 0, n_rot = 0, max_depth = 0;
     DevForest dev{};
@@ -269,6 +312,7 @@ struct dh_predictor {
     // captured batch (hipGraph)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    bool graph_stale = false;        // the workspace a captured batch points into was reallocated: dh_graph_launch refuses
     // taps
     bool debug = false;
     int32_t *dbg_leaf = nullptr;
@@ -333,7 +377,15 @@ static int build_kernel_table(dh_predictor *p) {
     return DH_OK;
 }
 
+static void drop_graph(dh_predictor *p) {
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    p->graph_exec = nullptr; p->graph = nullptr;
+}
+
 static void free_workspace(dh_predictor *p) {
+    // a captured batch has the old workspace pointers baked in: replaying it would touch freed memory
+    if (p->graph_exec) { drop_graph(p); p->graph_stale = true; }
     void *ptrs[] = {p->box, p->win_patch, p->win_leaf, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
                     p->dbg_flags, p->dbg_guess, p->dbg_trace, p->dbg_steps, p->dbg_votes, p->dbg_vcount};
     for (void *q : ptrs)
@@ -350,9 +402,8 @@ static void free_workspace(dh_predictor *p) {
 extern "C" int dh_predictor_destroy(dh_predictor *p) {
     if (!p) return DH_OK;
     (void)hipSetDevice(p->device);
-    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    if (p->graph) (void)hipGraphDestroy(p->graph);
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
+    drop_graph(p);
     free_workspace(p);
     for (void *q : p->forest_allocs) (void)hipFree(q);
     if (p->kern_ord) (void)hipFree(p->kern_ord);
@@ -385,6 +436,7 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     if (!p) return fail(DH_ENOMEM, "out of host memory");
     p->device = device;
     p->params = *prm;
+    p->knobs = read_knobs();   // the only place the environment is read
     p->n_trees = (uint32_t)f->roots.size(); p->n_nodes = (uint32_t)f->nodes.size(); p->n_leaves = (uint32_t)f->leaf_prob.size();
     p->n_off = f->off_begin.back(); p->n_rot = f->rot_begin.back(); p->max_depth = f->max_depth;
     p->f_uniform = f->uniform; p->f_rw = f->rw; p->f_rh = f->rh;
@@ -437,8 +489,7 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     if (rc == DH_OK) rc = build_kernel_table(p);
     for (auto &e : p->ev)
         if (rc == DH_OK) hipstep(hipEventCreate(&e), "hipEventCreate");
-    p->chunks = 1;   // measured on MI355X: forked sub-batches do not overlap usefully (1.016 vs 1.022 ms), kept as a knob
-    if (const char *e = getenv("DH_CHUNKS")) p->chunks = std::max(1, std::min(DH_MAX_CHUNKS, atoi(e)));
+    p->chunks = p->knobs.chunks;   // measured on MI355X: forked sub-batches do not overlap usefully (1.016 vs 1.022 ms), kept as a knob
     if (rc == DH_OK) hipstep(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming), "hipEventCreate");
     for (int i = 0; i < DH_MAX_CHUNKS - 1; ++i) {
         if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->aux_stream[i], hipStreamNonBlocking), "hipStreamCreate");
@@ -478,10 +529,9 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
     const int step = (int)p->params.stepwidth, sw = (int)p->params.subimage_width, sh = (int)p->params.subimage_height;
     const int rw = g.uniform ? p->f_rw : 0, rh = g.uniform ? p->f_rh : 0;
     size_t budget = 79 * 1024;   // two 1024-thread workgroups per CU (160 KB LDS)
-    if (const char *e = getenv("DH_LDS_BUDGET_KB")) budget = (size_t)atoi(e) * 1024;
+    if (p->knobs.lds_budget_kb > 0) budget = (size_t)p->knobs.lds_budget_kb * 1024;
     budget = std::min<size_t>(budget, 158 * 1024);
-    int fx = 0, fy = 0;
-    if (const char *e = getenv("DH_TILE")) sscanf(e, "%d,%d", &fx, &fy);
+    const int fx = p->knobs.tile_x, fy = p->knobs.tile_y;
     long best = -1;
     for (int py = 1; py <= std::min(g.ny, 64); ++py)
         for (int px = 1; px <= std::min(g.nx, 64); ++px) {
@@ -522,8 +572,7 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
         const int bw = g.w - rw + 1, ow_max = (kBoxSpan - rw) & ~3;
         g.box_parts = (bw + ow_max - 1) / ow_max;
         g.box_ow = std::min(ow_max, ((bw + g.box_parts - 1) / g.box_parts + 3) & ~3);
-        int band = 64;
-        if (const char *e = getenv("DH_BOX_BAND")) band = std::max(1, atoi(e));
+        const int band = p->knobs.box_band;
         g.box_bands = (g.box_rows + band - 1) / band;
         g.box_oh = (g.box_rows + g.box_bands - 1) / g.box_bands;
     }
@@ -547,7 +596,7 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     if (g.npatch > 0) {
         // uniform-rectangle fast path: one rectangle size (<= 96 x 96, so a k_boxsum wave yields
         // >= 160 columns), rectangle sums fit i32
-        g.uniform = p->f_uniform && (long)p->f_rw * p->f_rh <= 32768 && p->f_rw <= kBoxMaxRect && p->f_rh <= kBoxMaxRect && !getenv("DH_FORCE_GENERAL");
+        g.uniform = p->f_uniform && (long)p->f_rw * p->f_rh <= 32768 && p->f_rw <= kBoxMaxRect && p->f_rh <= kBoxMaxRect && !p->knobs.force_general;
         rc = choose_tile(p, g);
         if (rc > 0) { g.uniform = false; rc = choose_tile(p, g); }   // no tile fits the uniform layout
         if (rc) return rc;
@@ -567,9 +616,7 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
         if (rc == DH_OK && hipMemset(p->box, 0, words * sizeof(uint32_t)) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box)");   // the slack columns stay 0
     }
     // one block, one memset per batch: hit counters | guess grids | tile flags | window counts | leaf histogram
-    uint32_t hist_max = DH_LEAF_HIST_MAX;
-    if (const char *e = getenv("DH_LEAF_HIST_MAX")) hist_max = (uint32_t)std::max(0, atoi(e));
-    const bool leaf_hist = p->n_leaves <= hist_max && !getenv("DH_NO_LEAF_HIST");
+    const bool leaf_hist = p->n_leaves <= p->knobs.leaf_hist_max && !p->knobs.no_leaf_hist;
     const size_t counter_words = (size_t)cap * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words + (size_t)g.tiles_x * g.tiles_y);
     STEP(dev_alloc(p, &p->counters, counter_words + (leaf_hist ? (size_t)cap * p->n_leaves : 0)));
     if (rc == DH_OK) p->leaf_hits = leaf_hist ? p->counters + counter_words : nullptr;
@@ -631,7 +678,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ba.ow = g.box_ow; ba.oh = g.box_oh; ba.parts = g.box_parts; ba.bands = g.box_bands;
         // LDS-ring instance (each pixel read once): 4 waves x (rh - 1) packed rows per workgroup, so about
         // 12 waves fit a CU; the bands are made as tall as keeps the whole launch resident at once
-        const bool ring_on = !getenv("DH_BOX_NO_RING");
+        const bool ring_on = !p->knobs.box_no_ring;
         if (ring_on && p->f_rh >= 2 && p->f_rh - 1 <= 28) {      // 4 x 28 x 512 B + the prefix rows < 64 KB
             const long waves_max = 12L * 256;
             int bands = (int)std::max(1L, std::min<long>(std::max(1, g.box_rows / 16), waves_max / std::max(1L, (long)n * g.box_parts)));
@@ -662,9 +709,10 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.nodes_u = p->nodes_u;
         ta.box = box; ta.box_plane = g.box_plane; ta.box_rows = g.box_rows;
         ta.tile_flags = tile_flags;
-        if (const char *e = getenv("DH_TRAV_STOP")) ta.stop_phase = atoi(e);
+#ifdef DH_PROFILING_KNOBS
+        ta.stop_phase = p->knobs.trav_stop;
         static unsigned long long *stamps = nullptr;
-        if (getenv("DH_TRAV_STAMPS")) {
+        if (p->knobs.trav_stamps) {
             if (!stamps) { HIP_TRY(hipMalloc((void **)&stamps, 64)); HIP_TRY(hipMemset(stamps, 0, 64)); }
             else {
                 unsigned long long hst[8];
@@ -674,6 +722,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
             }
             ta.dbg_stamps = stamps;
         }
+#endif
         ta.f = p->dev;
         const int tiles = g.tiles_x * g.tiles_y;
         uint32_t *win_count = p->counters + (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words) + (size_t)f0 * tiles;
@@ -695,7 +744,9 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
             ea.hit_count = hit_count; ea.hits_cap = p->hits_cap;
             ea.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
             ea.dbg_flags = ta.dbg_flags;
-            if (const char *e = getenv("DH_EMIT_STOP")) ea.stop = atoi(e);
+#ifdef DH_PROFILING_KNOBS
+            ea.stop = p->knobs.emit_stop;
+#endif
             HIP_TRY(dh_launch_emit(ea, s));
         }
     } else if (profile) HIP_TRY(hipEventRecord(p->ev[5], s));
@@ -709,7 +760,9 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         va.hit_count = hit_count; va.hits_cap = p->hits_cap;
         va.pos_grid = pos_grid; va.rot_grid = rot_grid;
         va.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
-        if (const char *e = getenv("DH_VOTE_STOP")) va.stop = atoi(e);
+#ifdef DH_PROFILING_KNOBS
+        va.stop = p->knobs.vote_stop;
+#endif
         HIP_TRY(dh_launch_vote(va, s));
     }
     if (profile) HIP_TRY(hipEventRecord(p->ev[2], s));
@@ -722,7 +775,9 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ca.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
         ca.pos_grid = pos_grid; ca.rot_grid = rot_grid; ca.kern_ord = p->kern_ord;
         ca.iterations = p->params.meanshift_iterations;
-        if (const char *e = getenv("DH_CL_STOP")) ca.stop = atoi(e);
+#ifdef DH_PROFILING_KNOBS
+        ca.stop = p->knobs.cl_stop;
+#endif
         ca.midp_guess = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
         ca.rot_guess = rot_guess ? rot_guess + (size_t)f0 * 3 : nullptr;
         ca.guess_mask = guess_mask ? guess_mask + f0 : nullptr;
@@ -737,14 +792,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
 // Largest number of frames whose hit records are resident at once (64 B x window positions x trees
 // per frame: 9 MB per frame at BASELINE config 2).  Larger batches are walked in slices on the same
 // stream, reusing the workspace.
-static int max_resident_frames() {
-    static int v = 0;
-    if (!v) {
-        v = 512;
-        if (const char *e = getenv("DH_MAX_RESIDENT_FRAMES")) v = std::max(1, atoi(e));
-    }
-    return v;
-}
+static int max_resident_frames(const dh_predictor *p) { return p->knobs.max_resident; }
 
 extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                                        const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
@@ -754,7 +802,7 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
     if (n < 0) return fail(DH_EINVAL, "negative batch size");
     DeviceGuard guard(p->device);
     if (!guard.ok) return fail(DH_EHIP, "cannot select device %d", p->device);
-    const int slice = p->debug ? n : std::min(n, max_resident_frames());   // the taps index the whole batch
+    const int slice = p->debug ? n : std::min(n, max_resident_frames(p));   // the taps index the whole batch
     int rc = reserve(p, slice, w, h);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream_;
@@ -804,7 +852,7 @@ extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, 
     if (n == 0) return DH_OK;
     if (n < 0) return fail(DH_EINVAL, "negative batch size");
     HIP_TRY(hipSetDevice(p->device));
-    const int slice = p->debug ? n : std::min(n, max_resident_frames());
+    const int slice = p->debug ? n : std::min(n, max_resident_frames(p));
     hipStream_t s = p->own_stream;
     for (int f0 = 0; f0 < n; f0 += slice) {      // host batches are staged slice by slice
         const int m = std::min(slice, n - f0);
@@ -829,9 +877,8 @@ extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, 
 // launches of one dh_predict_batch_device call are captured once and replayed with one host call.
 extern "C" int dh_graph_destroy(dh_predictor *p) {
     if (!p) return fail(DH_EINVAL, "NULL predictor");
-    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    if (p->graph) (void)hipGraphDestroy(p->graph);
-    p->graph_exec = nullptr; p->graph = nullptr;
+    drop_graph(p);
+    p->graph_stale = false;
     return DH_OK;
 }
 
@@ -841,7 +888,7 @@ extern "C" int dh_graph_capture(dh_predictor *p, const uint16_t *frames, int n, 
     if (n <= 0) return fail(DH_EINVAL, "batch size must be positive");
     if (p->debug || p->profiling) return fail(DH_ESTATE, "taps / profiling cannot be captured");
     HIP_TRY(hipSetDevice(p->device));
-    int rc = reserve(p, std::min(n, max_resident_frames()), w, h);   // every allocation happens before the capture starts
+    int rc = reserve(p, std::min(n, max_resident_frames(p)), w, h);   // every allocation happens before the capture starts
     if (rc) return rc;
     dh_graph_destroy(p);
     HIP_TRY(hipStreamSynchronize(p->own_stream));
@@ -858,6 +905,7 @@ extern "C" int dh_graph_capture(dh_predictor *p, const uint16_t *frames, int n, 
 
 extern "C" int dh_graph_launch(dh_predictor *p, void *stream) {
     if (!p) return fail(DH_EINVAL, "NULL predictor");
+    if (p->graph_stale) return fail(DH_ESTATE, "the captured batch is stale: the workspace was reallocated after dh_graph_capture (larger batch, other frame size or debug taps); capture again");
     if (!p->graph_exec) return fail(DH_ESTATE, "no captured batch (dh_graph_capture)");
     HIP_TRY(hipGraphLaunch(p->graph_exec, (hipStream_t)stream));
     return DH_OK;
@@ -927,7 +975,7 @@ extern "C" int dh_predict_mask_device(dh_predictor *p, const uint16_t *frames, i
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     DeviceGuard guard(p->device);
     if (!guard.ok) return fail(DH_EHIP, "cannot select device %d", p->device);
-    const int slice = std::min(n, max_resident_frames());
+    const int slice = std::min(n, max_resident_frames(p));
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
         int rc = aux_reserve(p, m, w, h, 0);
@@ -943,7 +991,7 @@ extern "C" int dh_hough_image_device(dh_predictor *p, const uint16_t *frames, in
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     DeviceGuard guard(p->device);
     if (!guard.ok) return fail(DH_EHIP, "cannot select device %d", p->device);
-    const int slice = std::min(n, max_resident_frames());
+    const int slice = std::min(n, max_resident_frames(p));
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
         int rc = aux_reserve(p, m, w, h, 0);
@@ -972,7 +1020,7 @@ extern "C" int dh_predict_mask(dh_predictor *p, const uint16_t *frames, int n, i
     if (!p || !frames || !mask) return fail(DH_EINVAL, "dh_predict_mask: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     HIP_TRY(hipSetDevice(p->device));
-    const int slice = std::min(n, max_resident_frames());
+    const int slice = std::min(n, max_resident_frames(p));
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
         const size_t ob = (size_t)m * w * h;
@@ -990,7 +1038,7 @@ extern "C" int dh_hough_image(dh_predictor *p, const uint16_t *frames, int n, in
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_hough_image: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     HIP_TRY(hipSetDevice(p->device));
-    const int slice = std::min(n, max_resident_frames());
+    const int slice = std::min(n, max_resident_frames(p));
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
         const size_t ob = (size_t)m * w * h * sizeof(uint16_t);
@@ -1078,6 +1126,14 @@ extern "C" int dh_debug_hit_counts(dh_predictor *p, uint32_t *out) {
     HIP_TRY(hipMemcpy(out, p->counters, (size_t)p->last_n * 4, hipMemcpyDeviceToHost));
     return DH_OK;
 }
+extern "C" int dh_debug_geometry(dh_predictor *p, int32_t out[10]) {
+    if (!p || !out) return fail(DH_EINVAL, "NULL argument");
+    if (p->cap_frames == 0) return fail(DH_ESTATE, "no workspace yet (dh_predictor_reserve or a batch)");
+    const Geom &g = p->geom;
+    const int32_t v[10] = {g.uniform ? 1 : 0, g.px, g.py, g.tiles_x, g.tiles_y, g.swz_log2, g.swz_q, g.ss_row, p->f_rw, p->f_rh};
+    memcpy(out, v, sizeof v);
+    return DH_OK;
+}
 extern "C" int dh_debug_guesses(dh_predictor *p, int32_t *out) {
     int rc = tap_ready_dbg(p);
     if (rc) return rc;
@@ -1099,6 +1155,8 @@ extern "C" int dh_debug_votes(dh_predictor *p, int frame, int which, int32_t *ou
     int rc = tap_ready(p);
     if (rc) return rc;
     if (frame < 0 || frame >= p->last_n || which < 0 || which > 1 || !count) return fail(DH_EINVAL, "bad frame / which / count");
+    // k_emit writes the rotation records only without the leaf histogram or with the taps on
+    if (which == 1 && p->leaf_hits && !p->dbg_valid) return fail(DH_ESTATE, "rotation votes need dh_debug_enable(1) before the batch");
     if (cap > 0xffffffffull) cap = 0xffffffffull;
     if (!p->dbg_vcount) { rc = dev_alloc(p, &p->dbg_vcount, 1); if (rc) return rc; }
     if (cap > p->dbg_votes_cap) {

@@ -18,6 +18,14 @@
 
 #define WAVE 64
 
+// Per-phase profiling switches (kernels cut short after phase N: results INVALID) exist only in builds with
+// -DDH_PROFILING_KNOBS (tools/pmc_phases.sh); the product library compiles them out.
+#ifdef DH_PROFILING_KNOBS
+#define KNOB_STOP(cond) (cond)
+#else
+#define KNOB_STOP(cond) false
+#endif
+
 // ------------------------------------------------------------------ Rust `as` casts
 // float -> int truncates toward zero, saturates, NaN -> 0.
 __device__ __forceinline__ int32_t f32_as_i32(float v) {
@@ -819,12 +827,16 @@ __device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32
     }
 }
 
+#ifdef DH_PROFILING_KNOBS
 #define STAMP(k)                                                                        \
     if (a.dbg_stamps && tid == 0) {                                                     \
         unsigned long long t_ = clock64();                                              \
         atomicAdd(&a.dbg_stamps[k], t_ - t_prev);                                        \
         t_prev = t_;                                                                    \
     }
+#else
+#define STAMP(k)
+#endif
 
 template <bool UNI>
 __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
@@ -838,7 +850,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // XCDs round-robin -- is x + 8 * (tile + tiles * z), so no division is needed to decode it.
     const int frame = (int)blockIdx.z * 8 + (int)blockIdx.x;
     const int tile = (int)blockIdx.y;
-    if (frame >= a.n_frames || a.stop_phase == 9) return;
+    if (frame >= a.n_frames || KNOB_STOP(a.stop_phase == 9)) return;
     const int ty = div_small(tile, a.tiles_x, 1.0f / (float)a.tiles_x), tx = tile - ty * a.tiles_x;
     const int cx = min(a.px, a.nx - tx * a.px), cy = min(a.py, a.ny - ty * a.py);
     const float r_cx = 1.0f / (float)cx;
@@ -853,7 +865,9 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     uint32_t *misc = agp + a.px * a.py;        // [0] n_active, [4] any pixel
 
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
+#ifdef DH_PROFILING_KNOBS
     unsigned long long t_prev = a.dbg_stamps ? clock64() : 0ull;
+#endif
 
     // ---- phase 1.  General path: summed-area table of the footprint, modulo 2^32 (footprints of up
     // to 128 x 128 and 256 x 64 pixels are scanned in registers with DPP wave scans, anything else
@@ -923,7 +937,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
             }
         return;
     }
-    if (a.stop_phase == 1) return;
+    if (KNOB_STOP(a.stop_phase == 1)) return;
     STAMP(0)
 
     // ---- phase 2: background gate (prediction.rs:567-571).  Active windows are appended to the tile's
@@ -977,7 +991,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         }
     }
     __syncthreads();
-    if (a.stop_phase == 3) return;
+    if (KNOB_STOP(a.stop_phase == 3)) return;
     STAMP(1)
     const int n_active = (int)misc[0];
     if (tid == 0) a.win_count[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] = (uint32_t)n_active;   // zero for skipped tiles (host memset)
@@ -1069,7 +1083,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
         if (__ballot(tile < 0) == 0ull) break;
     }
     const bool live = tile >= 0;
-    if (__ballot(live) == 0ull || a.stop == 1) return;
+    if (__ballot(live) == 0ull || KNOB_STOP(a.stop == 1)) return;
     if (!live) { tile = 0; slot = 0; }
     const int T = (int)a.f.n_trees;
     const size_t w = (size_t)tile * pp + slot;                           // slot in the frame's window list
@@ -1136,7 +1150,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
             }
         }
     }
-    if (a.stop == 2) return;
+    if (KNOB_STOP(a.stop == 2)) return;
     // slots in the frame's hit arrays: one atomic per wave, exclusive prefix of the lanes' counts
     const uint32_t incl = wave_incl_scan(cnt);
     const uint32_t wave_total = __shfl(incl, WAVE - 1);
@@ -1282,7 +1296,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         for (int i = tid; i < a.h; i += VOTE_THREADS) gyt[i] = (uint8_t)((uint32_t)i * DH_GRID / (uint32_t)a.h);
     }
     __syncthreads();
-    if (a.stop == 1) return;
+    if (KNOB_STOP(a.stop == 1)) return;
     const HitRec *hits = a.hits + (size_t)frame * a.hits_cap;
     const HitBox *box = a.hit_box + (size_t)frame * a.hits_cap;
     const HitRot *hr = a.hit_rot + (size_t)frame * a.hits_cap;
@@ -1333,7 +1347,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
             if (acc) atomicAdd(&pos[last], acc);
         }
     }
-    if (a.stop == 2) return;
+    if (KNOB_STOP(a.stop == 2)) return;
     if (a.leaf_hits) {
         // Rotation votes depend only on the leaf (prediction.rs:601-636): with the per-frame leaf histogram the
         // 20^3 guess grid is the sum over the leaves that voted of count x v x (their distinct cells); u32
@@ -1350,7 +1364,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         }
     }
     __syncthreads();
-    if (a.stop == 3) return;
+    if (KNOB_STOP(a.stop == 3)) return;
     uint32_t *gp = a.pos_grid + (size_t)frame * DH_POSGRID, *gr = a.rot_grid + (size_t)frame * DH_GRID3;
     for (int i = tid; i < DH_POSGRID; i += VOTE_THREADS) if (pos[i]) atomicAdd(&gp[i], pos[i]);
     for (int i = tid; i < DH_GRID3; i += VOTE_THREADS) if (rot[i]) atomicAdd(&gr[i], rot[i]);
@@ -1487,7 +1501,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
     int32_t *trace = a.dbg_trace ? a.dbg_trace + ((size_t)which * a.n_frames + frame) * (a.iterations + 1) * 3 : nullptr;
     if (trace && tid < 3) trace[tid] = pos[tid];
 
-    if (a.stop == 1) return;
+    if (KNOB_STOP(a.stop == 1)) return;
     // ---------------- mean shift (meanshift.rs:328-407)
     uint32_t n_hits = a.hit_count[frame];
     if (n_hits > a.hits_cap) n_hits = a.hits_cap;
@@ -1618,7 +1632,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             }
         }
         __syncthreads();
-        if (a.stop == 2) return;
+        if (KNOB_STOP(a.stop == 2)) return;
         // ---- order-preserving compaction of the window's non-zero cells; window cell index
         // (dx*20+dy)*20+dz = chunk*1024 + tid is the reference's summation order
 #pragma unroll 1
@@ -1687,7 +1701,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             }
             __syncthreads();
         }
-        if (a.stop == 3) return;
+        if (KNOB_STOP(a.stop == 3)) return;
         const float den = s_acc[3];
         if (den == 0.0f) break;                                                              // :385-388
         int32_t np0 = f32_as_i32(__fdiv_rn(s_acc[0], den)), np1 = f32_as_i32(__fdiv_rn(s_acc[1], den)),

@@ -238,6 +238,12 @@ class HoughPrediction:
         check(self._lib.dh_debug_guesses(self._ph, vp(out)))
         return out
 
+    def debug_geometry(self) -> dict:
+        out = np.zeros(10, dtype=np.int32)
+        check(self._lib.dh_debug_geometry(self._ph, vp(out)))
+        keys = ("uniform", "px", "py", "tiles_x", "tiles_y", "swz_log2", "swz_q", "ss_row", "rw", "rh")
+        return dict(zip(keys, (int(x) for x in out)))
+
     def debug_hit_counts(self, n: int) -> np.ndarray:
         out = np.zeros(n, dtype=np.uint32)
         check(self._lib.dh_debug_hit_counts(self._ph, vp(out)))

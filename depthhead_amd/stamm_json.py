@@ -17,8 +17,9 @@ payloads -- the key of the tree list, the node container's field names, and whic
 their known keys and recovers the tree shape from the JSON nesting (any chain of single-key wrapper
 objects, a node object = one NodeParam payload + exactly two child subtrees).  The two children are
 taken in document order unless their keys say otherwise (left/right, zero/one, false/true, 0/1);
-`one_child` states which of them `Binar::One` follows -- "right" by default (SURVEY.md Appendix B:
-"Binar::Zero -> left, Binar::One -> right", believed, unverified).  A flat layout (nodes in an array
+`one_child` states which of them `Binar::One` follows; it is a REQUIRED argument of `import_json`
+(SURVEY.md Appendix B believes "Binar::Zero -> left, Binar::One -> right", unverified -- so no default
+is offered, and `flip_suspect` gives a sanity check on a labelled frame).  A flat layout (nodes in an array
 referring to each other by index) is accepted too.  `export_json` writes the nested layout this
 importer assumes, so a converted model can be inspected and round-tripped.
 """
@@ -202,8 +203,15 @@ def _flat_nodes(tree):
     return None
 
 
-def import_json(text: str, one_child: str = "right") -> tuple[Forest, ModelParams]:
-    """JSON of a serialised `HoughPrediction` -> (Forest, ModelParams)."""
+def import_json(text: str, *, one_child: str) -> tuple[Forest, ModelParams]:
+    """JSON of a serialised `HoughPrediction` -> (Forest, ModelParams).
+
+    `one_child` ("left" / "right": the child `Binar::One` selects) has NO default: stamm 0.2.0 is not
+    vendored, so the convention cannot be verified here, and a silently flipped import yields
+    plausible but wrong poses.  The caller states it; `check_child_convention` below helps to tell
+    the two apart on a labelled frame.  PARITY UNPINNED (stamm layout / child order)."""
+    if one_child not in ("left", "right"):
+        raise ValueError("one_child must be 'left' or 'right' (which child Binar::One selects; unverifiable here -- see INTEGRATION.md)")
     doc = json.loads(text)
     try:
         params = ModelParams(doc["stepwidth"], doc["subimage_width"], doc["subimage_height"], doc["gaussian_sigma"],
@@ -261,3 +269,14 @@ def export_json(forest: Forest, params: ModelParams, one_child: str = "right") -
            "forest": {"subtrees": [{"root": sub(int(r))} for r in forest.roots]},
            "meanshift_iterations": params.meanshift_iterations}
     return json.dumps(doc)
+
+
+def flip_suspect(poses_as_imported, poses_flipped, truth_mid, tol_mm: float = 150.0) -> bool:
+    """Sanity check against a flipped `Binar::One` convention on labelled frames (e.g. BIWI ground
+    truth, `depthhead_amd.biwi`): given the head positions predicted with the model as imported and
+    with `one_child` flipped, returns True when the FLIPPED import lands within `tol_mm` of the
+    ground truth on more frames than the import under test -- i.e. the caller's `one_child` is
+    probably wrong.  A heuristic for humans, not a parity statement."""
+    a = np.linalg.norm(np.asarray(poses_as_imported, dtype=np.float64) - np.asarray(truth_mid, dtype=np.float64), axis=-1)
+    b = np.linalg.norm(np.asarray(poses_flipped, dtype=np.float64) - np.asarray(truth_mid, dtype=np.float64), axis=-1)
+    return int((b <= tol_mm).sum()) > int((a <= tol_mm).sum())

@@ -191,6 +191,23 @@ def test_product_code_never_touches_the_oracle():
                 assert "pyoracle" not in txt and "dh_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
 
 
+def test_product_library_has_no_profiling_knobs(hip_lib):
+    """The kernel-truncating switches (DH_TRAV_STOP, ... -- "results invalid") are compiled only into the
+    tools/ twin built with -DDH_PROFILING_KNOBS; the product library does not even contain their names, and
+    the environment is read in exactly one function (read_knobs, called by dh_predictor_create)."""
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"DH_TRAV_STOP", b"DH_EMIT_STOP", b"DH_VOTE_STOP", b"DH_CL_STOP", b"DH_TRAV_STAMPS"):
+        assert name not in blob, name
+    assert b"DH_FORCE_GENERAL" in blob     # (the result-preserving diagnostic switches are still there)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    api = open(os.path.join(root, "depthhead_amd", "csrc", "dh_api.hip")).read()
+    body = api[api.index("static Knobs read_knobs()"):]
+    body = body[:body.index("\n}\n") + 3]
+    assert api.count("getenv(") == body.count("getenv(") > 0, "getenv outside read_knobs()"
+    for fn in ("dh_kernels.hip", "dh_biwi.hip"):
+        assert "getenv(" not in open(os.path.join(root, "depthhead_amd", "csrc", fn)).read()
+
+
 def test_cpp_example_compiles_and_links(tmp_path):
     """examples/predict_frame.cpp -- a host with no Python in it -- builds against the header and links the
     shared library (it needs a GPU to run: tests/test_gpu_parity.py::test_cpp_example_runs)."""

@@ -1,0 +1,323 @@
+"""GPU tests added in round 2: regressions for the bugs the out-of-suite fuzz found, BASELINE configs at
+their stated sizes, and the hardening of the runtime (stale hipGraph, tap gating, profiling knobs).
+
+All comparisons are HIP path (through the C ABI) vs the CPU oracle, bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from depthhead_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp_mod(hip_lib):
+    from depthhead_amd import prediction
+    return prediction
+
+
+def _poses_equal(a, ref):
+    return np.array_equal(a["mid_point"], ref["mid_point"]) and np.array_equal(a["rotation"], ref["rotation"])
+
+
+# ------------------------------------------------------------------ fuzz case 114070 (edge-tile region copy)
+def _fuzz_case(case):
+    """tools/fuzz_parity.py's default-mode recipe for one case number (same seeds, same draws)."""
+    rs = np.random.RandomState(777000 + case)
+    sw, sh = int(rs.randint(16, 97)), int(rs.randint(16, 97))
+    w, h = sw + int(rs.randint(1, 420)), sh + int(rs.randint(1, 300))
+    step = int(rs.choice([1, 2, 3, 4, 4, 4, 5, 6, 8, 10, 12]))
+    trees, depth = int(rs.randint(1, 18)), int(rs.randint(1, 12))
+    mixed = rs.rand() < 0.2
+    forest = synth.synth_forest(trees, depth, 9000 + case, patch=(sw, sh), rect_scale=float(rs.uniform(0.1, 0.6)),
+                                rect_scale_max=float(rs.uniform(0.6, 0.9)) if mixed else None,
+                                full_depth=int(rs.randint(0, depth + 1)), p_split=float(rs.uniform(0.4, 0.95)))
+    model = synth.ModelParams(stepwidth=step, subimage_width=sw, subimage_height=sh,
+                              gaussian_sigma=float(rs.uniform(0.5, 30.0)), meanshift_iterations=int(rs.randint(0, 25)))
+    n = int(rs.randint(1, 4))
+    frames = np.stack([synth.biwi_like(max(w, 96), max(h, 96), 19000 + case * 7 + i)[:h, :w] for i in range(n)]).copy()
+    if rs.rand() < 0.25:
+        frames[0] = (rs.rand(h, w) < 0.01) * rs.randint(1, 65536, (h, w))
+    if rs.rand() < 0.25:
+        frames[-1, :, : w // 2] = 0
+    f = float(rs.uniform(200, 900))
+    K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], dtype=np.float32)
+    return forest, model, frames.astype(np.uint16), K, (w, h, sw, sh, step, mixed)
+
+
+def _edge_tile_is_cut(geo, model, w):
+    """True when the tiling has a last tile column that is cut by the right frame edge such that it owns fewer
+    16-byte groups per plane than a full tile: the case the direct-to-LDS region copy got wrong before fc33f8a
+    (it copied all q/4 groups of every plane and so read past the 4 words of slack behind the image's last
+    column, dh_kernels.hip `q4_tile`)."""
+    step, sw = model.stepwidth, model.subimage_width
+    lw = sw // 2
+    nx = (w - (sw - lw) - lw + step - 1) // step
+    cx_last = nx - (geo["tiles_x"] - 1) * geo["px"]
+    m = 1 << geo["swz_log2"]
+    bw_last = (cx_last - 1) * step + sw - geo["rw"] + 1
+    q4_tile = (((bw_last + m - 1) >> geo["swz_log2"]) + 3) >> 2
+    return geo["uniform"] == 1 and geo["px"] % 4 == 0 and geo["tiles_x"] > 1 and q4_tile < geo["swz_q"] // 4
+
+
+def test_fuzz_case_114070_edge_tile_region_copy(hp_mod, oracle):
+    """gpurun_out/fuzz2.log (round 1): `MISMATCH case 114070 ... 215x193 patch 38x19 step 1 ... mixed False` -- two
+    frames wrong without a fault.  The same seeds rebuild the case; the tiling is asserted to contain the cut edge
+    tile, so the test fails by construction on the pre-fix predicate (`lane < pieces` only)."""
+    forest, model, frames, K, (w, h, sw, sh, step, mixed) = _fuzz_case(114070)
+    assert (w, h, sw, sh, step, mixed) == (215, 193, 38, 19, 1, False)
+    n = frames.shape[0]
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.debug_enable(True)
+        poses = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        geo = hp.debug_geometry()
+        leaf = hp.debug_leaf_indices(n, w, h)
+        pg, rg = hp.debug_grids(n)
+    assert _edge_tile_is_cut(geo, model, w), geo
+    for i in range(n):
+        ref = oracle.predict(forest, model, frames[i], K)
+        assert np.array_equal(leaf[i], ref.leaf_idx), f"frame {i}: leaf indices"
+        assert np.array_equal(pg[i], ref.pos_grid) and np.array_equal(rg[i], ref.rot_grid)
+        assert np.array_equal(poses["mid_point"][i], ref.mid_point) and np.array_equal(poses["rotation"][i], ref.rotation)
+
+
+@pytest.mark.parametrize("w,step,rect_scale", [(215, 1, 0.3), (333, 4, 0.3), (250, 2, 0.25), (258, 8, 0.4)])
+def test_cut_edge_tiles_constructed(hp_mod, oracle, w, step, rect_scale):
+    """Widths chosen so that the last tile column is cut (asserted from the runtime's own tiling), for every
+    de-interleave factor m = 1, 2, 4, 8; the frames carry non-zero pixels up to the right edge and in the last rows,
+    so the cut tiles are walked."""
+    h = 170
+    forest = synth.synth_forest(5, 8, synth.FOREST_SEED_BASE + 500 + step, patch=(40, 32), rect_scale=rect_scale)
+    model = synth.ModelParams(stepwidth=step, subimage_width=40, subimage_height=32)
+    frames = np.stack([synth.biwi_like(640, 480, 6100 + i)[150:150 + h, 200:200 + w] for i in range(3)]).copy()
+    frames[2, :, w - 60:] = np.maximum(frames[2, :, w - 60:], 900)      # right edge fully populated
+    frames[1, h - 40:, :] = np.maximum(frames[1, h - 40:, :], 700)      # bottom rows too
+    K = synth.default_intrinsic(w, h)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.debug_enable(True)
+        poses = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        geo = hp.debug_geometry()
+        leaf = hp.debug_leaf_indices(3, w, h)
+        flags = hp.debug_patch_flags(3, w, h)
+    assert _edge_tile_is_cut(geo, model, w), (geo, w, step)
+    for i in range(3):
+        ref = oracle.predict(forest, model, frames[i], K)
+        assert np.array_equal(leaf[i], ref.leaf_idx), f"frame {i}: leaf indices"
+        assert np.array_equal(flags[i], ref.patch_flags)
+        assert np.array_equal(poses["mid_point"][i], ref.mid_point) and np.array_equal(poses["rotation"][i], ref.rotation)
+
+
+# ------------------------------------------------------------------ BASELINE configs at their stated sizes
+@pytest.fixture(scope="module")
+def forest_c3():
+    return synth.synth_forest(50, 20, synth.FOREST_SEED_BASE + 3)     # 1.4 M nodes, 408 MB: nodes spill L2, no leaf histogram
+
+
+def test_config3_as_stated(hp_mod, oracle, forest_c3):
+    """BASELINE configs[2] exactly: 50 trees, depth 20, stride 2, 640x480 -- 56 000 windows x 50 trees = 2.8 M walks per
+    frame.  Two frames stage by stage against the oracle (leaf ids, flags, grids, guesses, trace, pose)."""
+    from test_gpu_parity import _check_frames
+    assert forest_c3.n_trees == 50 and forest_c3.n_leaves > 16384
+    model = synth.ModelParams(stepwidth=2)
+    frames = synth.biwi_batch(2, 640, 480, first=40)
+    _check_frames(hp_mod, oracle, forest_c3, model, frames, synth.default_intrinsic(), full=False)
+
+
+def test_config3_batch32_properties(hp_mod, oracle, forest_c3):
+    """configs[2] at its batch size (32 frames): deterministic, independent of batch order and
+    composition, and equal to the oracle on every frame (SAT mode: O(1) per node)."""
+    model = synth.ModelParams(stepwidth=2)
+    base = synth.biwi_batch(16, 640, 480, first=200)
+    frames = np.concatenate([base, base[::-1]])
+    perm = np.random.RandomState(3).permutation(32)
+    K = synth.default_intrinsic()
+    with hp_mod.HoughPrediction(forest_c3, model, device=0) as hp:
+        a = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        b = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        c = hp.predict_batch(frames[perm], hp_mod.IntrinsicMatrix(K))
+        d = hp.predict_batch(frames[5:8], hp_mod.IntrinsicMatrix(K))
+    assert a.tobytes() == b.tobytes()
+    assert _poses_equal(c, a[perm]) and _poses_equal(d, a[5:8])
+    assert _poses_equal(a[16:], a[:16][::-1])
+    ref = oracle.predict_batch(forest_c3, model, base, K)
+    assert _poses_equal(a[:16], ref)
+
+
+@pytest.mark.parametrize("n", [512, 513])
+def test_config4_per_rank_load(hp_mod, oracle, n):
+    """BASELINE configs[3]'s per-rank load: 512 config-2 frames in ONE call (= the resident-slice limit) and 513
+    (slice boundary: 512 + 1), through the host entry point; properties + a 16-frame oracle sample."""
+    forest = synth.fit_forest(10, 15, synth.FOREST_SEED_BASE + 2)
+    model = synth.ModelParams(stepwidth=4)
+    base = synth.biwi_batch(32, 640, 480, first=300)
+    idx = np.arange(n) % 32
+    frames = base[idx]
+    K = synth.default_intrinsic()
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        a = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        b = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+    assert a.tobytes() == b.tobytes()
+    ref = oracle.predict_batch(forest, model, base[:16], K)
+    assert _poses_equal(a[:16], ref)
+    assert _poses_equal(a, a[:32][idx])            # every replica of a frame gives the same pose, also across the slice boundary
+    assert np.all(a["reserved"] == 0)
+
+
+# ------------------------------------------------------------------ hardening
+def test_stale_graph_is_refused(hp_mod, oracle):
+    """A captured batch has workspace pointers baked in; a later call that reallocates the workspace (larger batch)
+    must make dh_graph_launch fail with DH_ESTATE instead of replaying onto freed memory.  After a new capture the
+    replay matches the oracle again."""
+    torch = pytest.importorskip("torch")
+    from depthhead_amd._lib import POSE_DTYPE, DepthheadError
+    forest = synth.synth_forest(6, 10, synth.FOREST_SEED_BASE + 8)
+    model = synth.ModelParams(stepwidth=2)
+    w, h, n = 320, 240, 2
+    K = synth.default_intrinsic(w, h)
+    intr = hp_mod.IntrinsicMatrix(K)
+    dev = torch.device("cuda:0")
+    a = synth.biwi_batch(n, w, h, first=90)
+    big = synth.biwi_batch(4, w, h, first=20)
+    fr = torch.from_numpy(a.view(np.int16)).to(dev)
+    out = torch.zeros(n * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.graph_capture(fr.data_ptr(), n, w, h, intr, out.data_ptr())
+        hp.graph_launch(st.cuda_stream)
+        st.synchronize()
+        p4 = hp.predict_batch(big, intr)                       # n = 4 > 2: the workspace is reallocated
+        assert _poses_equal(p4, oracle.predict_batch(forest, model, big, K))
+        with pytest.raises(DepthheadError) as ei:
+            hp.graph_launch(st.cuda_stream)
+        assert ei.value.code == -6 and "stale" in str(ei.value)
+        hp.graph_capture(fr.data_ptr(), n, w, h, intr, out.data_ptr())
+        hp.graph_launch(st.cuda_stream)
+        st.synchronize()
+        poses = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)
+        assert _poses_equal(poses, oracle.predict_batch(forest, model, a, K))
+        # other ways to lose the workspace: another frame size (predict_mask), the debug taps
+        hp.predict_mask(synth.biwi_batch(1, 200, 160, first=3))
+        with pytest.raises(DepthheadError):
+            hp.graph_launch(st.cuda_stream)
+
+
+def test_rotation_vote_tap_needs_debug(hp_mod):
+    """dh_debug_votes(which = 1) reads rotation records that k_emit only writes without the leaf histogram or with
+    the taps on: without dh_debug_enable it must return DH_ESTATE, not read uninitialised records."""
+    from depthhead_amd._lib import DepthheadError
+    forest = synth.fit_forest(4, 8, synth.FOREST_SEED_BASE + 9, n_frames=8, subset=800)
+    model = synth.ModelParams(stepwidth=4)
+    frames = synth.biwi_batch(2, 320, 240)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.predict_batch(frames, hp_mod.IntrinsicMatrix(synth.default_intrinsic(320, 240)))
+        with pytest.raises(DepthheadError) as ei:
+            hp.debug_votes(0, 1, cap=1024)
+        assert ei.value.code == -6
+        hp.debug_votes(0, 0, cap=1 << 16)                       # position votes need no taps
+        hp.debug_enable(True)
+        hp.predict_batch(frames, hp_mod.IntrinsicMatrix(synth.default_intrinsic(320, 240)))
+        assert hp.debug_votes(0, 1).shape[1] == 4
+
+
+def test_stray_profiling_environment_cannot_change_poses(hp_mod, oracle):
+    """The kernel-truncating profiling switches are compiled out of the product library: an inherited
+    DH_TRAV_STOP / DH_EMIT_STOP / DH_VOTE_STOP / DH_CL_STOP cannot alter results."""
+    forest = synth.fit_forest(6, 10, synth.FOREST_SEED_BASE + 9, n_frames=12, subset=1500)
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 320, 240
+    frames = synth.biwi_batch(3, w, h)
+    K = synth.default_intrinsic(w, h)
+    ref = oracle.predict_batch(forest, model, frames, K)
+    stray = {"DH_TRAV_STOP": "1", "DH_EMIT_STOP": "1", "DH_VOTE_STOP": "1", "DH_CL_STOP": "1", "DH_TRAV_STAMPS": "1"}
+    old = {k: os.environ.get(k) for k in stray}
+    os.environ.update(stray)
+    try:
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            got = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert _poses_equal(got, ref)
+    assert np.any(ref["mid_point"] != 0)
+
+
+# ------------------------------------------------------------------ product mode (no parity taps)
+def _product_mode_check(hp_mod, oracle, forest, model, frames, K, env=None):
+    """Product mode (dh_debug_enable never called): every tap that works without it -- both guess grids, the
+    per-frame hit count, every position vote -- and the pose, against the oracle."""
+    n = frames.shape[0]
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            poses = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+            pg, rg = hp.debug_grids(n)
+            hits = hp.debug_hit_counts(n)
+            votes = [hp.debug_votes(i, 0) for i in range(n)]
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    total_hits = 0
+    for i in range(n):
+        ref = oracle.predict(forest, model, frames[i], K)
+        gated = (ref.patch_flags & 2) != 0
+        lf = ref.leaf_idx[gated]
+        prob = forest.leaf_prob[lf]
+        nv = forest.off_begin[lf + 1] - forest.off_begin[lf]
+        # a hit record = a (gated window, leaf with prob > 0) pair whose leaf passes a covariance gate; every such leaf has votes
+        assert hits[i] <= int(((prob > 0) & (nv > 0)).sum()), f"frame {i}: more hit records than voting leaves of gated windows"
+        total_hits += int(hits[i])
+        assert np.array_equal(pg[i], ref.pos_grid), f"frame {i}: 20x20 guess grid"
+        assert np.array_equal(rg[i], ref.rot_grid), f"frame {i}: 20^3 guess grid"
+        assert np.array_equal(hp_mod.aggregate_votes(votes[i]), ref.mid_cells), f"frame {i}: position accumulator"
+        assert np.array_equal(poses["mid_point"][i], ref.mid_point) and np.array_equal(poses["rotation"][i], ref.rotation), f"frame {i}: pose"
+    return total_hits
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_product_mode_matches_the_oracle(hp_mod, oracle, general):
+    """Most stage-wise tests run with the parity taps on; this one runs the configuration users run (taps off: no dense
+    leaf array, rotation votes through the leaf histogram) on both traversal paths."""
+    forest = synth.fit_forest(10, 12, synth.FOREST_SEED_BASE + 21, n_frames=16, subset=2500)
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 400, 300
+    frames = synth.biwi_batch(3, w, h, first=50)
+    hits = _product_mode_check(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), {"DH_FORCE_GENERAL": "1"} if general else {})
+    assert hits > 0                                             # some windows pass the gate: the test sees votes
+
+
+def test_window_means_at_the_gate(hp_mod, oracle):
+    """Leaf probabilities engineered so that window means sit exactly on, one ulp above and one ulp below 0.7
+    (prediction.rs:582-584 sums in tree order in f64 and compares with > 0.7)."""
+    rs = np.random.RandomState(5)
+    forest = synth.synth_forest(10, 6, synth.FOREST_SEED_BASE + 22)
+    prob = forest.leaf_prob
+    voting = prob > 0
+    choices = np.array([0.7, np.nextafter(0.7, 1.0), np.nextafter(0.7, 0.0), 0.75, 0.65, 1.0, 0.7000001, 0.6999999])
+    prob[voting] = choices[rs.randint(0, choices.size, int(voting.sum()))]
+    model = synth.ModelParams(stepwidth=3)
+    w, h = 320, 240
+    frames = synth.biwi_batch(3, w, h, first=60)
+    _product_mode_check(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h))
+
+
+def test_leaf_probabilities_outside_the_unit_interval(hp_mod, oracle):
+    """A hand-edited model with leaf 'probabilities' above 1 (the reference does not validate them)."""
+    forest = synth.synth_forest(6, 6, synth.FOREST_SEED_BASE + 23)
+    prob = forest.leaf_prob
+    prob[prob > 0] *= 1.9
+    assert prob.max() > 1.0
+    model = synth.ModelParams(stepwidth=4)
+    frames = synth.biwi_batch(2, 320, 240, first=64)
+    _product_mode_check(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(320, 240))

@@ -17,13 +17,13 @@ def _same(a, b):
 
 def _canon(f):
     """Renumber nodes / leaves in the importer's order (depth-first, first child first) via a round trip."""
-    return stamm_json.import_json(stamm_json.export_json(f, synth.ModelParams()))[0]
+    return stamm_json.import_json(stamm_json.export_json(f, synth.ModelParams()), one_child="right")[0]
 
 
 def test_roundtrip_nested_layout(oracle):
     f = synth.synth_forest(3, 6, 41)
     p = synth.ModelParams(stepwidth=7, gaussian_sigma=6.5, meanshift_iterations=11)
-    g, q = stamm_json.import_json(stamm_json.export_json(f, p))
+    g, q = stamm_json.import_json(stamm_json.export_json(f, p), one_child="right")
     assert (q.stepwidth, q.subimage_width, q.subimage_height, q.gaussian_sigma, q.meanshift_iterations) == (7, 80, 80, 6.5, 11)
     assert g.n_nodes == f.n_nodes and g.n_leaves == f.n_leaves and g.max_depth() == f.max_depth()
     assert _same(g, _canon(g))                                    # importing is idempotent on its own output
@@ -54,7 +54,7 @@ def test_other_nestings_give_the_same_forest(style):
     p = synth.ModelParams()
     doc = json.loads(stamm_json.export_json(f, p))
     doc["forest"] = {"trees": [{"tree_function": {"max_depth": 15}, "root": _retag(t["root"], style)} for t in doc["forest"]["subtrees"]]}
-    g, _ = stamm_json.import_json(json.dumps(doc))
+    g, _ = stamm_json.import_json(json.dumps(doc), one_child="right")
     assert _same(g, _canon(f))
 
 
@@ -85,7 +85,7 @@ def test_flat_layout_and_child_convention():
         trees.append({"root": emit(int(r)), "nodes": arr})
     doc = {"stepwidth": 4, "subimage_width": 80, "subimage_height": 80, "gaussian_sigma": 8.0, "meanshift_iterations": 20,
            "forest": {"subtrees": trees}}
-    g, _ = stamm_json.import_json(json.dumps(doc))
+    g, _ = stamm_json.import_json(json.dumps(doc), one_child="right")
     assert _same(g, _canon(f))
     # the unverifiable part is explicit: with Binar::One -> left every node's children swap
     h, _ = stamm_json.import_json(json.dumps(doc), one_child="left")
@@ -96,7 +96,23 @@ def test_flat_layout_and_child_convention():
 
 def test_rejects_other_documents():
     with pytest.raises(ValueError):
-        stamm_json.import_json('{"stepwidth": 4}')
+        stamm_json.import_json('{"stepwidth": 4}', one_child="right")
     with pytest.raises(ValueError):
         stamm_json.import_json(json.dumps({"stepwidth": 4, "subimage_width": 80, "subimage_height": 80, "gaussian_sigma": 8.0,
-                                           "meanshift_iterations": 20, "forest": {"subtrees": []}}))
+                                           "meanshift_iterations": 20, "forest": {"subtrees": []}}), one_child="right")
+
+
+def test_child_convention_must_be_stated():
+    """stamm's Binar::One -> child convention is unverifiable here (crate not vendored): the importer offers
+    no default, so a model cannot be imported with a silently guessed (possibly flipped) convention."""
+    f = synth.synth_forest(2, 4, 77)
+    text = stamm_json.export_json(f, synth.ModelParams())
+    with pytest.raises(TypeError):
+        stamm_json.import_json(text)
+    with pytest.raises(ValueError):
+        stamm_json.import_json(text, one_child="up")
+    a, _ = stamm_json.import_json(text, one_child="right")
+    b, _ = stamm_json.import_json(text, one_child="left")
+    assert np.array_equal(a.nodes["child_one"], b.nodes["child_zero"]) and np.array_equal(a.nodes["child_zero"], b.nodes["child_one"])
+    truth = np.array([[0.0, 0.0, 1000.0]] * 3)
+    assert stamm_json.flip_suspect(truth + 400.0, truth + 5.0, truth) and not stamm_json.flip_suspect(truth + 5.0, truth + 400.0, truth)
