@@ -33,6 +33,8 @@ import torch
 
 KERNEL_OF = {"boxsum_ms": "k_boxsum", "traverse_ms": "k_traverse", "emit_ms": "k_emit", "vote_ms": "k_vote", "cluster_ms": "k_cluster"}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+SCLK_HZ = 2.4e9         # max shader clock (MI355X_MICROARCH.md); the chip may run lower under load, so *_frac are lower bounds
+N_CUS, N_SIMDS = 256, 1024
 
 
 def parse():
@@ -57,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (other configs, PCIe-inclusive rates): profiling runs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
+    ap.add_argument("--dump-poses", default=None, help="rank 0 writes the gathered pose records of the last timed step (all ranks, rank order) as .npy")
     return ap.parse_args()
 
 
@@ -102,44 +105,22 @@ def main():
     distinct = synth.biwi_batch(nd, W, H, first=rank * nd)               # different frames on every rank
     frames_np = np.concatenate([distinct] * ((NF + nd - 1) // nd))[:NF]
     frames = torch.from_numpy(frames_np.view(np.int16)).to(dev)          # resident in HBM before timing
-    # two pose buffers: the gather of step i (on RCCL's stream) overlaps the kernels of step i + 1, which
-    # therefore write the other buffer; a buffer is reused only after its gather has been waited for
-    pose_bufs = [torch.zeros(NF * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(2)]
-    poses = pose_bufs[0]
-    gdev = dev if args.backend == "nccl" else torch.device("cpu")
-    gathered = [torch.zeros(world * NF * POSE_DTYPE.itemsize, dtype=torch.uint8, device=gdev) for _ in range(2)] if world > 1 else None
-    pending = [None, None]
-    counter = [0]
-
     hp = HoughPrediction(forest, model, device=local_rank)
     hp.reserve(NF, W, H)
     stream = torch.cuda.current_stream(dev)
-
+    # the shard -> predict -> gather loop is the package's (depthhead_amd.dist.ShardedPredictor): two pose buffers, the
+    # RCCL all-gather of step i overlaps the kernels of step i + 1
+    from depthhead_amd.dist import ShardedPredictor
+    sp = ShardedPredictor(hp, NF, W, H, intr, device=dev)
+    poses = sp.pose_bufs[0]
     if args.graph:
-        hp.graph_capture(frames.data_ptr(), NF, W, H, intr, poses.data_ptr())
+        sp.capture(frames.data_ptr())
 
     def step():
-        b = counter[0] & 1 if (world > 1 and not args.graph) else 0
-        counter[0] += 1
-        if pending[b] is not None:
-            pending[b].wait()                      # stream-side wait for NCCL; the buffer is free again
-            pending[b] = None
-        if args.graph:
-            hp.graph_launch(stream.cuda_stream)
-        else:
-            hp.predict_batch_device(frames.data_ptr(), NF, W, H, intr, pose_bufs[b].data_ptr(), stream=stream.cuda_stream)
-        if world > 1:
-            src = pose_bufs[b] if args.backend == "nccl" else pose_bufs[b].cpu()
-            pending[b] = dist.all_gather_into_tensor(gathered[b], src, async_op=True)   # gather of the pose records
+        sp.submit(frames.data_ptr(), stream)
 
-    def fence():
-        for i in range(2):
-            if pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    fence = sp.fence
+    gdev = dev if args.backend == "nccl" else torch.device("cpu")
 
     for _ in range(args.warmup):
         step()
@@ -153,6 +134,25 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    gpu_poses = sp.last_poses() if rank == 0 else None     # gathered records of the last timed step (all ranks, rank order)
+    if args.dump_poses and rank == 0:
+        np.save(args.dump_poses, gpu_poses)
+    # run-to-run spread: the same K-step region twice more (untimed for `value`, which stays the first region)
+    repeats = [elapsed / args.steps * 1e3]
+    if not args.no_extras:
+        for _ in range(2):
+            fence()
+            tr = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            e = time.perf_counter() - tr
+            if world > 1:
+                t = torch.tensor([e], dtype=torch.float64, device=gdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                e = float(t.item())
+            repeats.append(e / args.steps * 1e3)
 
     # ---- per-kernel durations with HIP events on the launch stream (outside the timed region)
     hp.set_profiling(True)
@@ -169,12 +169,18 @@ def main():
     # ---- PCIe-inclusive rate: the same batch through the host-buffer entry point (H2D copy of the
     # frames, compute, D2H of the poses).  Reported next to `value`, never as `value`.
     pcie_fps = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         hp.predict_batch(frames_np, intr)
         t1 = time.perf_counter()
         for _ in range(3):
             hp.predict_batch(frames_np, intr)
         pcie_fps = 3 * NF / (time.perf_counter() - t1)
+
+    also = None
+    if world == 1 and not args.no_extras and not custom_workload():
+        hp.close()
+        hp = None
+        also = other_configs(args, dev, stream)
 
     if rank == 0:
         total_frames = world * NF * args.steps
@@ -184,8 +190,31 @@ def main():
         # algorithmic bytes per launch: every depth pixel read once, one pose
         # record written per frame, the forest read once per launch
         b_alg = NF * (W * H * 2 + 36) + forest.nbytes()
-        traffic, traffic_src = pmc_traffic(KERNEL_OF[dom])
+        prof = Profiles()
+        traffic = prof.traffic(KERNEL_OF[dom])
         achieved = b_alg / (acc[dom] * 1e-3) / 1e9 if acc[dom] > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": KERNEL_OF[dom],
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "traffic_source": prof.source if traffic is not None else None, "profile_head": prof.head,
+                "profile_matches_build": prof.matches, "kernel_source_sha256_16": prof.build_hash,
+                "algorithmic_bytes_per_launch": b_alg, "launch_ms": round(acc[dom], 4),
+                # the same algorithmic bytes over the whole step (all five kernels): what the job as a whole reaches
+                "whole_step_frac": round(b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
+                "note": "achieved = algorithmic bytes of the launch / duration of the dominant kernel (live HIP events). "
+                        "That kernel is not HBM-bound (DESIGN.md section 5): its own measured traffic over its own time is in "
+                        "kernels_hbm, its vector-issue load in valu_issue_frac; k_boxsum is the kernel at the HBM roof"}
+        sq = prof.sq(KERNEL_OF[dom])
+        if sq and acc[dom] > 0:
+            cycles = acc[dom] * 1e-3 * SCLK_HZ
+            # second roof of the dominant kernel: a wave64 VALU instruction holds its SIMD's vector issue for 4 cycles
+            roof["valu_issue_frac"] = round(sq.get("SQ_INSTS_VALU", 0.0) * 4 / (N_SIMDS * cycles), 4)
+            if sq.get("SQ_LDS_IDX_ACTIVE"):
+                roof["lds_busy_frac"] = round(sq["SQ_LDS_IDX_ACTIVE"] / (N_CUS * cycles), 4)
+                roof["lds_bank_conflict_share"] = round(sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_LDS_IDX_ACTIVE"], 4)
+            if sq.get("SQ_INSTS_VMEM_RD"):
+                # 16-byte-per-lane gathers occupy the CU's vector-memory path ~16 cycles each (profiles/r02_ubench_gather.txt)
+                roof["vmem_issue_frac"] = round(sq["SQ_INSTS_VMEM_RD"] * 16 / (N_CUS * cycles), 4)
         out = {
             "metric": "depth frames/sec (640x480, 10-tree forest)",
             "value": round(fps, 1),
@@ -205,42 +234,150 @@ def main():
                                    f"80x80 patches, 20 mean-shift iterations",
                        "frames_per_gpu": NF, "width": W, "height": H, "trees": args.trees, "max_depth": args.depth,
                        "stride": args.stride, "parallelism": f"frame-sharded x{world}, RCCL all-gather of poses"},
-            "roofline": {"bound": "hbm", "kernel": KERNEL_OF[dom],
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": b_alg, "launch_ms": round(acc[dom], 4)},
+            "roofline": roof,
+            "repeat_ms_per_step": [round(r, 4) for r in repeats],
             "kernels_ms": kernels,
             # measured HBM traffic (PMC, gfx950-corrected) over the live duration of every kernel: shows which
             # kernel actually runs at memory speed (k_boxsum) and which are latency / issue bound
             "kernels_hbm": {KERNEL_OF[k]: {"traffic": t, "GB/s": round(t / (acc[k] * 1e-3) / 1e9, 1), "frac": round(t / (acc[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                            for k in KERNEL_OF for t in [pmc_traffic(KERNEL_OF[k])[0]] if t and acc[k] > 0},
+                            for k in KERNEL_OF for t in [prof.traffic(KERNEL_OF[k])] if t and acc[k] > 0},
             "pcie_inclusive_frames_per_s": None if pcie_fps is None else round(pcie_fps, 1),
         }
+        if also is not None:
+            out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(forest, model, frames_np, K, args.cpu_seconds)
+            out["cpu_baseline"], ref_poses = cpu_baseline(forest, model, frames_np, K, args.cpu_seconds)
+            # the second half of BASELINE.json's metric ("pose L2 vs ref"): the GPU poses of the last timed step against
+            # the oracle's for the very same frames (both are integer-grid values: the difference must be exactly 0)
+            dm = np.linalg.norm(gpu_poses["mid_point"].astype(np.float64) - ref_poses["mid_point"].astype(np.float64), axis=1)
+            dr = np.linalg.norm(gpu_poses["rotation"] - ref_poses["rotation"], axis=1)
+            out["pose_l2_max_vs_oracle"] = {"mid_point_mm": float(dm.max()), "rotation_rad": float(dr.max()), "frames": int(dm.size),
+                                            "tolerance": 1e-4}
         print(json.dumps(out), flush=True)
 
-    hp.close()
+    if hp is not None:
+        hp.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the most recent committed PMC summary (separate
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, default workload only).
+WORKLOAD_FLAGS = ("--frames", "--width", "--height", "--trees", "--depth", "--stride", "--forest", "--graph")
+
+
+def custom_workload() -> bool:
+    return any(a in sys.argv for a in WORKLOAD_FLAGS)
+
+
+def kernel_source_hash() -> str:
+    """Identifies the kernels a profile was taken on: sha256 over the kernel / runtime sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("dh_kernels.hip", "dh_api.hip", "dh_internal.h"):
+        h.update(open(os.path.join(ROOT, "depthhead_amd", "csrc", fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+class Profiles:
+    """The committed rocprofv3 counter summaries under profiles/ (written by tools/profile_round.sh from separate
+    `--pmc` passes of this same command, default workload).  A summary is only used when the sources it records
+    (`_meta.kernel_source_sha256_16`) are the sources of this build: otherwise `traffic` is null, never stale.
     gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-byte requests at 64 bytes, so reads are
     doubled; both counters are in KB."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if not files or any(a in sys.argv for a in ("--frames", "--width", "--height", "--trees", "--depth", "--stride", "--forest")):
-        return None, None
-    try:
-        d = json.load(open(files[-1]))
-        e = next(v for k, v in d.items() if kernel in k)
-        return int((2 * e["FETCH_SIZE_KB_avg_per_launch"] + e["WRITE_SIZE_KB_avg_per_launch"]) * 1024), os.path.basename(files[-1])
-    except (StopIteration, KeyError, ValueError, OSError):
-        return None, None
+
+    def __init__(self):
+        import glob
+        self.build_hash = kernel_source_hash()
+        self.mem, self.sqd, self.source, self.head, self.matches = None, None, None, None, False
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), key=os.path.getmtime)
+        for f in reversed(files):
+            try:
+                d = json.load(open(f))
+            except (OSError, ValueError):
+                continue
+            meta = d.get("_meta", {})
+            if self.source is None:
+                self.source, self.head = os.path.basename(f), meta.get("git_head")
+            if meta.get("kernel_source_sha256_16") == self.build_hash:
+                self.source, self.head, self.matches, self.mem = os.path.basename(f), meta.get("git_head"), True, d
+                try:
+                    self.sqd = json.load(open(f.replace("_pmc_summary.json", "_sq_summary.json")))
+                except (OSError, ValueError):
+                    self.sqd = None
+                break
+        if custom_workload():
+            self.mem = self.sqd = None
+
+    def traffic(self, kernel: str):
+        if not self.mem:
+            return None
+        try:
+            e = next(v for k, v in self.mem.items() if kernel in k)
+            return int((2 * e["FETCH_SIZE_KB_avg_per_launch"] + e["WRITE_SIZE_KB_avg_per_launch"]) * 1024)
+        except (StopIteration, KeyError, ValueError):
+            return None
+
+    def sq(self, kernel: str):
+        if not self.sqd:
+            return None
+        return next((v for k, v in self.sqd.items() if kernel in k), None)
+
+
+def rate(hp, frames_t, n, w, h, intr, stream, steps=5, warmup=2, graph=False):
+    """frames/s of `steps` device-resident batches (host wall clock around synchronised launches)."""
+    out = torch.zeros(n * 40, dtype=torch.uint8, device=frames_t.device)
+    if graph:
+        hp.graph_capture(frames_t.data_ptr(), n, w, h, intr, out.data_ptr())
+    run = (lambda: hp.graph_launch(stream.cuda_stream)) if graph else \
+          (lambda: hp.predict_batch_device(frames_t.data_ptr(), n, w, h, intr, out.data_ptr(), stream=stream.cuda_stream))
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    return round(steps * n / (time.perf_counter() - t0), 1)
+
+
+def other_configs(args, dev, stream):
+    """The other BASELINE configs and variants on this one GPU, a few untimed-for-`value` steps each, so that the
+    driver's line carries them (frames/s).  Same generators and seeds as the parity tests."""
+    from depthhead_amd import synth
+    from depthhead_amd.prediction import HoughPrediction, IntrinsicMatrix
+    res = {}
+    W, H = 640, 480
+    intr = IntrinsicMatrix(synth.default_intrinsic(W, H))
+    base = synth.biwi_batch(64, W, H)
+    fr256 = torch.from_numpy(np.concatenate([base] * 4).view(np.int16)).to(dev)
+    fitted = synth.fit_forest(10, 15, synth.FOREST_SEED_BASE + 2)
+    rnd = synth.synth_forest(10, 15, synth.FOREST_SEED_BASE + 2)
+
+    def one(forest, stride, frames_t, n, w, h, intr_, env=None, graph=False, steps=5):
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            with HoughPrediction(forest, synth.ModelParams(stepwidth=stride), device=dev.index or 0) as hp:
+                hp.reserve(n, w, h)
+                return rate(hp, frames_t, n, w, h, intr_, stream, steps=steps, graph=graph)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    res["synth_forest_10_15"] = one(rnd, 4, fr256, 256, W, H, intr)                 # BASELINE.md section 4's random stress forest
+    res["c1_stride10"] = one(fitted, 10, fr256, 256, W, H, intr)                    # configs[0] geometry (the trainer's step width)
+    res["general_path"] = one(fitted, 4, fr256, 256, W, H, intr, env={"DH_FORCE_GENERAL": "1"})   # mixed-rectangle traversal, forced
+    small = torch.from_numpy(synth.biwi_batch(64, 320, 240).view(np.int16)).to(dev)
+    intr_s = IntrinsicMatrix(synth.default_intrinsic(320, 240))
+    res["c5_320x240_s1_graph"] = one(fitted, 1, small, 64, 320, 240, intr_s, graph=True)   # configs[4] on one GPU, hipGraph replay
+    res["c5_320x240_s1_single_frame_graph"] = one(fitted, 1, small, 1, 320, 240, intr_s, graph=True, steps=50)
+    c3 = synth.synth_forest(50, 20, synth.FOREST_SEED_BASE + 3)
+    res["c3_50x20_s2_32f"] = one(c3, 2, fr256, 32, W, H, intr, steps=3)              # configs[2]: 50 trees, depth 20, stride 2, batch 32
+    res["unit"] = "frames/s"
+    return res
 
 
 def host_cores() -> int:
@@ -284,13 +421,13 @@ def cpu_baseline(forest, model, frames_np, K, target_s):
     tf = time.perf_counter() - t0
     t0 = time.perf_counter()
     for _ in range(reps):
-        po.predict_batch(forest, model, frames_np, K, rect_mode=po.RECT_SAT, threads=cores)
+        ref = po.predict_batch(forest, model, frames_np, K, rect_mode=po.RECT_SAT, threads=cores)
     ts = time.perf_counter() - t0
     return {"value": round(n / tf, 2), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"the benchmark's {frames_np.shape[0]} frames x {reps} passes, frame-parallel OpenMP over {cores} threads; "
                       f"value = faithful O(area) rectangle loops as src/types.rs:317-339; sat_value = same results with a "
                       f"summed-area table (the fair CPU ceiling)",
-            "sat_value": round(n / ts, 2), "faithful_s": round(tf, 2), "sat_s": round(ts, 2)}
+            "sat_value": round(n / ts, 2), "faithful_s": round(tf, 2), "sat_s": round(ts, 2)}, ref
 
 
 if __name__ == "__main__":

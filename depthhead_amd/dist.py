@@ -60,3 +60,88 @@ def poses_from_bytes(buf) -> np.ndarray:
     if hasattr(buf, "cpu"):
         buf = buf.cpu().numpy()
     return np.frombuffer(np.ascontiguousarray(buf).tobytes(), dtype=POSE_DTYPE)
+
+
+def predict_stream(hp, frames, intrinsic, group=None) -> np.ndarray:
+    """Frame-sharded `predict_parameter_parallel` over a stream every rank can see (a host array or a
+    memory-mapped file of [N, H, W] uint16 frames): rank r predicts frames [r*N/R, (r+1)*N/R) with its own
+    predictor `hp` (any object with `predict_batch(frames, intrinsic)` returning POSE_DTYPE records -- a
+    `HoughPrediction` on this rank's GPU), then ONE all-gather of the 40-byte pose records hands every rank
+    the poses of all N frames in stream order.  No data-path collective."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return hp.predict_batch(np.asarray(frames), intrinsic)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_total = len(frames)
+    a, b = shard_range(n_total, rank, world)
+    local = hp.predict_batch(np.ascontiguousarray(frames[a:b]), intrinsic) if b > a else np.zeros(0, dtype=POSE_DTYPE)
+    buf = torch.from_numpy(np.frombuffer(local.tobytes(), dtype=np.uint8).copy())
+    backend = dist.get_backend(group)
+    if backend == "nccl":                      # RCCL moves device buffers
+        buf = buf.to(torch.device("cuda", torch.cuda.current_device()))
+    return poses_from_bytes(gather_poses(buf, n_total, group))
+
+
+class ShardedPredictor:
+    """The steady-state form of `predict_stream` for device-resident shards (what `bench.py --gpus N` times):
+    this rank's `n_local` frames already sit in HBM; `submit()` enqueues the local batch on `stream` and starts
+    the all-gather of its pose records (on RCCL's own stream, asynchronous); two pose / gather buffers alternate
+    so that the gather of step i overlaps the kernels of step i + 1.  `wait()` returns the gathered records of
+    the oldest outstanding step.  With `backend == "gloo"` (rehearsal on one device, or CPU-only hosts) the
+    records are staged through host memory.  World size 1: no collective at all."""
+
+    def __init__(self, hp, n_local: int, w: int, h: int, intrinsic, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.hp, self.n_local, self.w, self.h, self.intrinsic, self.group = hp, n_local, w, h, intrinsic, group
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.on_device = self.dist is None or self.dist.get_backend(group) == "nccl"
+        nb = n_local * POSE_BYTES
+        self.pose_bufs = [torch.zeros(nb, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        gdev = self.device if self.on_device else torch.device("cpu")
+        self.gathered = [torch.zeros(self.world * nb, dtype=torch.uint8, device=gdev) for _ in range(2)] if self.world > 1 else None
+        self.pending = [None, None]
+        self.count = 0
+        self.graph = False
+
+    def capture(self, frames_ptr: int):
+        """Replay the local batch from a hipGraph (launch-bound configs).  One pose buffer then: a replay
+        writes where the capture wrote, so each step waits for its own gather before the next replay."""
+        self.hp.graph_capture(frames_ptr, self.n_local, self.w, self.h, self.intrinsic, self.pose_bufs[0].data_ptr())
+        self.graph = True
+
+    def submit(self, frames_ptr: int, stream) -> int:
+        """Enqueue one step; returns the buffer index it uses."""
+        b = self.count & 1 if (self.world > 1 and not self.graph) else 0
+        self.count += 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()                      # stream-side wait for RCCL; the buffer is free again
+            self.pending[b] = None
+        if self.graph:
+            self.hp.graph_launch(stream.cuda_stream)
+        else:
+            self.hp.predict_batch_device(frames_ptr, self.n_local, self.w, self.h, self.intrinsic, self.pose_bufs[b].data_ptr(),
+                                         stream=stream.cuda_stream)
+        if self.world > 1:
+            src = self.pose_bufs[b] if self.on_device else self.pose_bufs[b].cpu()
+            self.pending[b] = self.dist.all_gather_into_tensor(self.gathered[b], src, group=self.group, async_op=True)
+        return b
+
+    def fence(self):
+        import torch
+        for i in range(2):
+            if self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None
+        if self.world > 1:
+            self.dist.barrier(group=self.group)
+        torch.cuda.synchronize(self.device)
+
+    def last_poses(self) -> np.ndarray:
+        """Gathered pose records (all ranks' shards in rank order) of the most recent step; call after fence()."""
+        b = (self.count - 1) & 1 if (self.world > 1 and not self.graph) else 0
+        return poses_from_bytes(self.gathered[b] if self.world > 1 else self.pose_bufs[b])

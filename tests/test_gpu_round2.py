@@ -321,3 +321,42 @@ def test_leaf_probabilities_outside_the_unit_interval(hp_mod, oracle):
     model = synth.ModelParams(stepwidth=4)
     frames = synth.biwi_batch(2, 320, 240, first=64)
     _product_mode_check(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(320, 240))
+
+
+# ------------------------------------------------------------------ the N > 1 control flow on the HIP library
+def test_two_rank_bench_rehearsal_on_one_gpu(oracle, hip_lib, tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), with
+    `--backend gloo` so that both ranks share this box's one GPU: the shard -> predict (HIP library) -> all-gather loop
+    of depthhead_amd.dist.ShardedPredictor runs end to end, and the gathered poses of both ranks equal the oracle's for
+    their shards.  A fresh child process, never an exec of this one."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "poses.npy")
+    nf, w, h, trees, depth = 8, 320, 240, 6, 10
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--frames", str(nf),
+           "--width", str(w), "--height", str(h), "--trees", str(trees), "--depth", str(depth), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras", "--dump-poses", dump]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    from depthhead_amd._lib import POSE_DTYPE
+    got = np.load(dump)
+    assert got.dtype == POSE_DTYPE and got.shape == (2 * nf,)
+    forest = synth.fit_forest(trees, depth, synth.FOREST_SEED_BASE + 2)
+    model = synth.ModelParams(stepwidth=4)
+    K = synth.default_intrinsic(w, h)
+    for rank in range(2):
+        frames = synth.biwi_batch(nf, w, h, first=rank * nf)          # bench.py's frames of that rank
+        ref = oracle.predict_batch(forest, model, frames, K)
+        assert _poses_equal(got[rank * nf:(rank + 1) * nf], ref), f"rank {rank}"

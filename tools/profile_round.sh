@@ -14,7 +14,6 @@ OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-HEAD=$(cat "$REPO/.git_head" 2>/dev/null || echo unknown)
 python3 "$REPO/bench.py" --steps 20 --warmup 3 $EXTRA > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 echo "bench done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extras $EXTRA > "$OUT/${TAG}_stats.log" 2>&1
@@ -55,7 +54,9 @@ for k, d in acc.items():
         else:
             e[c] = round(sum(v) / len(v), 1)
             e["launches"] = len(v)
+head_file = os.path.join(root, ".git_head")      # written by tools/gpu.sh before the snapshot leaves (the box has no .git)
 meta = {"tag": tag, "kernel_source_sha256_16": kernel_hash(),
+        "git_head": open(head_file).read().strip() if os.path.exists(head_file) else None,
         "note": "averages per launch over the bench's launches; FETCH_SIZE is in KB and under-reports wide reads by 2x on gfx950 "
                 "(MI355X_MICROARCH.md, HBM); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves"}
 mem["_meta"] = meta
