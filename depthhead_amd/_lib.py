@@ -42,7 +42,7 @@ class Timing(C.Structure):
 EXPORTS = [
     "dh_last_error", "dh_version", "dh_forest_create", "dh_forest_destroy", "dh_forest_info",
     "dh_predictor_create", "dh_predictor_destroy", "dh_predictor_update_sigma", "dh_predictor_sigma",
-    "dh_predict_batch", "dh_predict_batch_device", "dh_predictor_reserve", "dh_patch_grid",
+    "dh_predict_batch", "dh_predict_batch_device", "dh_predict_batch_rle", "dh_biwi_decode_depth_device", "dh_host_alloc", "dh_host_free", "dh_predictor_reserve", "dh_patch_grid",
     "dh_predict_mask", "dh_predict_mask_device", "dh_hough_image", "dh_hough_image_device",
     "dh_biwi_decode_depth", "dh_biwi_parse_cal", "dh_biwi_parse_pose",
     "dh_graph_capture", "dh_graph_launch", "dh_graph_destroy",
@@ -98,3 +98,17 @@ def vp(x):
     if isinstance(x, np.ndarray):
         return C.c_void_p(x.ctypes.data)
     return C.c_void_p(int(x))
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """A numpy array in page-locked host memory (dh_host_alloc): frame batches filled in place are uploaded by
+    asynchronous DMA at PCIe speed.  The memory is released when the array (and every view of it) is gone."""
+    import weakref
+    lib = load()
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape))
+    ptr = C.c_void_p()
+    check(lib.dh_host_alloc(C.c_size_t(max(1, count * dt.itemsize)), C.byref(ptr)))
+    raw = (C.c_uint8 * max(1, count * dt.itemsize)).from_address(ptr.value)
+    weakref.finalize(raw, lib.dh_host_free, C.c_void_p(ptr.value))
+    return np.frombuffer(raw, dtype=dt, count=count).reshape(shape)

@@ -11,8 +11,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <functional>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dh_internal.h"
@@ -220,6 +223,7 @@ struct DeviceGuard {
 
 // ------------------------------------------------------------------ predictor
 #define DH_MAX_CHUNKS 8
+#define DH_STAGE_EVENTS 16       // upload chunks in flight per slice
 // Knobs::leaf_hist_max = 16384: per-frame leaf histogram for the rotation gather (64 KB per frame at most); larger forests
                                  // rarely hit a leaf twice per frame and walk the hit records instead (measured: 35 k leaves is a loss)
 #define DH_MIN_CHUNK_FRAMES 16
@@ -238,7 +242,8 @@ struct Knobs {
     int box_band = 64;                // DH_BOX_BAND
     int max_resident = 512;           // DH_MAX_RESIDENT_FRAMES
     int chunks = 1;                   // DH_CHUNKS
-    int staging_depth = 2;            // DH_STAGING_DEPTH: pinned staging buffers of the host entry point (1 = serial)
+    int stage_chunk = 64;             // DH_STAGE_CHUNK: frames per upload chunk of the host entry points (copy of chunk k + 1 overlaps the kernels of chunk k)
+    int host_threads = 8;             // DH_HOST_THREADS: host threads that validate / pack run-length coded payloads
 #ifdef DH_PROFILING_KNOBS
     int trav_stop = 0, emit_stop = 0, vote_stop = 0, cl_stop = 0;
     bool trav_stamps = false;
@@ -257,7 +262,8 @@ static Knobs read_knobs() {
     k.box_band = std::max(1, geti("DH_BOX_BAND", 64));
     k.max_resident = std::max(1, geti("DH_MAX_RESIDENT_FRAMES", 512));
     k.chunks = std::max(1, std::min(8, geti("DH_CHUNKS", 1)));
-    k.staging_depth = std::max(1, std::min(4, geti("DH_STAGING_DEPTH", 2)));
+    k.stage_chunk = std::max(1, geti("DH_STAGE_CHUNK", 64));
+    k.host_threads = std::max(1, std::min(64, geti("DH_HOST_THREADS", (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())))));
 #ifdef DH_PROFILING_KNOBS
     k.trav_stop = geti("DH_TRAV_STOP", 0); k.emit_stop = geti("DH_EMIT_STOP", 0);
     k.vote_stop = geti("DH_VOTE_STOP", 0); k.cl_stop = geti("DH_CL_STOP", 0);
@@ -280,6 +286,16 @@ struct dh_predictor {
     void *nodes_u = nullptr;     // 16-byte compact nodes for the current region layout (uniform path)
     long long nodes_u_key = 0;   // (ss_row, swizzle) the compact nodes were built for
     hipStream_t own_stream = nullptr;
+    hipStream_t copy_stream = nullptr;    // host entry points: uploads run here, ahead of the kernels on own_stream
+    hipEvent_t ev_stage[DH_STAGE_EVENTS] = {};   // chunk k uploaded (recorded on an upload stream, waited for on own_stream)
+    hipEvent_t ev_slice = nullptr;        // the kernels that read the staging buffers are done (recorded on own_stream)
+    // run-length coded input (dh_predict_batch_rle): pinned staging + device copies of payload blob and run table
+    uint8_t *pin_blob = nullptr;  size_t pin_blob_cap = 0;
+    uint2 *pin_runs = nullptr;    size_t pin_runs_cap = 0;
+    uint32_t *pin_begin = nullptr; size_t pin_begin_cap = 0;
+    uint8_t *dev_blob = nullptr;  size_t dev_blob_cap = 0;
+    uint2 *dev_runs = nullptr;    size_t dev_runs_cap = 0;
+    uint32_t *dev_begin = nullptr; size_t dev_begin_cap = 0;
     int chunks = 1;                       // sub-batches per call (env DH_CHUNKS)
     hipStream_t aux_stream[DH_MAX_CHUNKS - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_join[DH_MAX_CHUNKS - 1] = {};
@@ -412,6 +428,15 @@ extern "C" int dh_predictor_destroy(dh_predictor *p) {
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     for (auto &e : p->ev_join) if (e) (void)hipEventDestroy(e);
     for (auto &st : p->aux_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
+    for (auto &e : p->ev_stage) if (e) (void)hipEventDestroy(e);
+    if (p->ev_slice) (void)hipEventDestroy(p->ev_slice);
+    if (p->pin_blob) (void)hipHostFree(p->pin_blob);
+    if (p->pin_runs) (void)hipHostFree(p->pin_runs);
+    if (p->pin_begin) (void)hipHostFree(p->pin_begin);
+    if (p->dev_blob) (void)hipFree(p->dev_blob);
+    if (p->dev_runs) (void)hipFree(p->dev_runs);
+    if (p->dev_begin) (void)hipFree(p->dev_begin);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     delete p;
     return DH_OK;
@@ -491,6 +516,10 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
         if (rc == DH_OK) hipstep(hipEventCreate(&e), "hipEventCreate");
     p->chunks = p->knobs.chunks;   // measured on MI355X: forked sub-batches do not overlap usefully (1.016 vs 1.022 ms), kept as a knob
     if (rc == DH_OK) hipstep(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming), "hipEventCreate");
+    if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto &e : p->ev_stage)
+        if (rc == DH_OK) hipstep(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    if (rc == DH_OK) hipstep(hipEventCreateWithFlags(&p->ev_slice, hipEventDisableTiming), "hipEventCreate");
     for (int i = 0; i < DH_MAX_CHUNKS - 1; ++i) {
         if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->aux_stream[i], hipStreamNonBlocking), "hipStreamCreate");
         if (rc == DH_OK) hipstep(hipEventCreateWithFlags(&p->ev_join[i], hipEventDisableTiming), "hipEventCreate");
@@ -845,7 +874,11 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
 }
 
 static int stage_frames(dh_predictor *p, const uint16_t *frames, int n, int w, int h);
+static int ensure_frame_staging(dh_predictor *p, size_t fbytes);
 
+// Host entry point.  The frames cross PCIe in chunks on copy_stream while the kernels of the previous chunk run on
+// own_stream (the path is PCIe-bound: 614 KB per frame in, 40 bytes out), so a batch takes about its upload time plus
+// the kernels of the last chunk.  The poses of a slice come back in one copy.
 extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                                 const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_batch: NULL argument");
@@ -853,19 +886,272 @@ extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, 
     if (n < 0) return fail(DH_EINVAL, "negative batch size");
     HIP_TRY(hipSetDevice(p->device));
     const int slice = p->debug ? n : std::min(n, max_resident_frames(p));
-    hipStream_t s = p->own_stream;
+    hipStream_t s = p->own_stream, cs = p->copy_stream;
+    const size_t fpx = (size_t)w * h;
     for (int f0 = 0; f0 < n; f0 += slice) {      // host batches are staged slice by slice
         const int m = std::min(slice, n - f0);
         int rc = reserve(p, m, w, h);
         if (rc) return rc;
-        rc = stage_frames(p, frames + (size_t)f0 * w * h, m, w, h);
+        rc = ensure_frame_staging(p, (size_t)m * fpx * sizeof(uint16_t));
         if (rc) return rc;
         if (midp_guess) HIP_TRY(hipMemcpyAsync(p->ws_midp, midp_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, s));
         if (rot_guess) HIP_TRY(hipMemcpyAsync(p->ws_rot, rot_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(double), hipMemcpyHostToDevice, s));
         if (guess_mask) HIP_TRY(hipMemcpyAsync(p->ws_mask, guess_mask + f0, (size_t)m, hipMemcpyHostToDevice, s));
-        rc = dh_predict_batch_device(p, p->ws_frames, m, w, h, K, midp_guess ? p->ws_midp : nullptr,
-                                     rot_guess ? p->ws_rot : nullptr, guess_mask ? p->ws_mask : nullptr, p->ws_poses, s);
+        // the parity taps describe ONE device batch: with them on, the slice is a single chunk
+        int chunk = p->debug ? m : std::min(m, p->knobs.stage_chunk);
+        chunk = std::max(chunk, (m + DH_STAGE_EVENTS / 2 - 1) / (DH_STAGE_EVENTS / 2));
+        // chunk sizes taper towards the end of the slice (each at most half of what is left, at least 16 frames): the
+        // kernels of the last chunk are the only ones no upload hides
+        int cstart[DH_STAGE_EVENTS + 1], nchunks = 0;
+        for (int c0 = 0; c0 < m && nchunks < DH_STAGE_EVENTS;) {
+            cstart[nchunks++] = c0;
+            const int left = m - c0;
+            int c = std::min(chunk, std::max(16, (left + 1) / 2));
+            if (nchunks == DH_STAGE_EVENTS || left - c < 8) c = left;
+            c0 += c;
+        }
+        cstart[nchunks] = m;
+        auto predict_chunk = [&](int c0, int cm) {
+            return dh_predict_batch_device(p, p->ws_frames + (size_t)c0 * fpx, cm, w, h, K, midp_guess ? p->ws_midp + (size_t)c0 * 3 : nullptr,
+                                           rot_guess ? p->ws_rot + (size_t)c0 * 3 : nullptr, guess_mask ? p->ws_mask + c0 : nullptr, p->ws_poses + c0, s);
+        };
+        if (nchunks == 1) {
+            // latency path (single frames, small batches): one copy on the compute stream itself
+            HIP_TRY(hipMemcpyAsync(p->ws_frames, frames + (size_t)f0 * fpx, (size_t)m * fpx * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+            rc = predict_chunk(0, m);
+            if (rc) { (void)hipStreamSynchronize(s); return rc; }
+        } else {
+            // Chunk k + 1 is uploaded on copy_stream while the kernels of chunk k run on own_stream.  From page-locked host
+            // memory (dh_host_alloc, or any buffer the caller registered with HIP) the copies are true asynchronous DMA and
+            // the whole batch takes its PCIe time; from pageable memory each copy is issued synchronously (the runtime pins,
+            // copies, unpins), which still overlaps the kernels but not the next chunk's preparation.
+            // (Measured and rejected: three host threads issuing the pageable chunk copies on three streams -- 60-82 k frames/s,
+            // erratic, against 80 k from this one thread: the pinning of the pages serialises in the driver.)
+            HIP_TRY(hipStreamWaitEvent(cs, p->ev_slice, 0));          // the previous slice's kernels have read the staging buffer
+            for (int k = 0; k < nchunks; ++k) {
+                const int c0 = cstart[k], cm = cstart[k + 1] - c0;
+                HIP_TRY(hipMemcpyAsync(p->ws_frames + (size_t)c0 * fpx, frames + (size_t)(f0 + c0) * fpx, (size_t)cm * fpx * sizeof(uint16_t), hipMemcpyHostToDevice, cs));
+                HIP_TRY(hipEventRecord(p->ev_stage[k], cs));
+                HIP_TRY(hipStreamWaitEvent(s, p->ev_stage[k], 0));
+                rc = predict_chunk(c0, cm);
+                if (rc) { (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(s); return rc; }
+            }
+        }
+        HIP_TRY(hipEventRecord(p->ev_slice, s));
+        HIP_TRY(hipMemcpyAsync(out + f0, p->ws_poses, (size_t)m * sizeof(dh_pose), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return DH_OK;
+}
+
+// Page-locked host memory for frame buffers: uploads from it are asynchronous DMA at PCIe speed.
+extern "C" int dh_host_alloc(size_t bytes, void **out) {
+    if (!out) return fail(DH_EINVAL, "dh_host_alloc: NULL argument");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return fail(DH_ENOMEM, "hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+    return DH_OK;
+}
+extern "C" int dh_host_free(void *ptr) {
+    if (ptr && hipHostFree(ptr) != hipSuccess) return fail(DH_EHIP, "hipHostFree");
+    return DH_OK;
+}
+
+// ------------------------------------------------------------------ run-length coded input (BIWI `.bin`, biwi.rs:81-103)
+static void parallel_for(int n, int threads, const std::function<void(int)> &fn) {
+    threads = std::max(1, std::min(threads, n));
+    if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<int> next{0};
+    auto body = [&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); };
+    std::vector<std::thread> pool;
+    pool.reserve(threads - 1);
+    try { for (int t = 1; t < threads; ++t) pool.emplace_back(body); } catch (...) { /* fewer workers: the caller's thread finishes the rest */ }
+    body();
+    for (auto &t : pool) t.join();
+}
+
+static inline uint32_t rd32(const uint8_t *q) { uint32_t v; memcpy(&v, q, 4); return v; }   // little-endian host (x86-64)
+
+// One pass over a payload's run headers with the checks of dh_biwi_decode_depth (where the reference returns an
+// io::Error or panics, biwi.rs:83-98).  runs == nullptr: count only.  Returns the number of non-empty runs or -1.
+static long rle_scan(const uint8_t *buf, size_t len, uint32_t W, uint32_t H, uint2 *runs, uint32_t dst0, uint32_t src0, char *err, size_t errn) {
+    const size_t total = (size_t)W * H;
+    size_t p = 0, pos = 8;
+    long cnt = 0;
+    while (p < total) {
+        if (len - pos < 4) { snprintf(err, errn, "depth payload truncated at byte %zu", pos); return -1; }
+        const uint32_t n_empty = rd32(buf + pos); pos += 4;
+        if ((size_t)n_empty > total - p) { snprintf(err, errn, "run of %u empty pixels overruns the image (reference panics, biwi.rs:92)", n_empty); return -1; }
+        p += n_empty;
+        if (len - pos < 4) { snprintf(err, errn, "depth payload truncated at byte %zu", pos); return -1; }
+        const uint32_t n_full = rd32(buf + pos); pos += 4;
+        if ((size_t)n_full > total - p) { snprintf(err, errn, "run of %u pixels overruns the image (reference panics, biwi.rs:97)", n_full); return -1; }
+        if ((len - pos) / 2 < n_full) { snprintf(err, errn, "depth payload truncated inside a run at byte %zu", pos); return -1; }
+        if (n_full) {
+            if (runs) runs[cnt] = make_uint2(dst0 + (uint32_t)p, src0 + (uint32_t)(pos >> 1));
+            ++cnt;
+        }
+        pos += (size_t)n_full * 2;
+        p += n_full;
+    }
+    return cnt;
+}
+
+template <typename T>
+static int grow_pinned(T **buf, size_t *cap, size_t need) {
+    if (need <= *cap) return DH_OK;
+    if (*buf) (void)hipHostFree(*buf);
+    *buf = nullptr; *cap = 0;
+    const size_t want = need + need / 4 + 4096;
+    void *q = nullptr;
+    hipError_t e = hipHostMalloc(&q, want * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(DH_ENOMEM, "hipHostMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+    *buf = (T *)q; *cap = want;
+    return DH_OK;
+}
+template <typename T>
+static int grow_device(T **buf, size_t *cap, size_t need) {
+    if (need <= *cap) return DH_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *cap = 0;
+    const size_t want = need + need / 4 + 4096;
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, want * sizeof(T));
+    if (e != hipSuccess) return fail(DH_ENOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+    *buf = (T *)q; *cap = want;
+    return DH_OK;
+}
+
+// Validates every payload, packs blob + run table into pinned memory and sizes the device buffers.  Nothing has been
+// launched when this fails.  blob_off[i] = byte offset of frame i's payload in the blob (16-byte aligned).
+static int rle_prepare(dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t *W_, uint32_t *H_,
+                       std::vector<size_t> &blob_off) {
+    if (n <= 0) return fail(DH_EINVAL, "batch size must be positive");
+    for (int i = 0; i < n; ++i) {
+        if (!bufs[i]) return fail(DH_EINVAL, "frame %d: NULL payload", i);
+        if (lens[i] < 8) return fail(DH_EINVAL, "frame %d: depth payload truncated in the header", i);      // read_u32 fails (biwi.rs:83-84)
+    }
+    const uint32_t W = rd32(bufs[0]), H = rd32(bufs[0] + 4);
+    if (W == 0 || H == 0 || (uint64_t)W * H > 0x7fffffffull) return fail(DH_ESIZE, "frame 0: unsupported image size %ux%u", W, H);
+    if ((uint64_t)n * W * H > 0xffffffffull) return fail(DH_ESIZE, "batch of %d frames of %ux%u exceeds 2^32 pixels; split it", n, W, H);
+    blob_off.assign((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) blob_off[i + 1] = blob_off[i] + ((lens[i] + 15) & ~(size_t)15);
+    if (blob_off[n] / 2 > 0xffffffffull) return fail(DH_ESIZE, "payloads exceed 8 GiB; split the batch");
+    // pass A: validate + count
+    std::vector<long> counts((size_t)n, 0);
+    std::vector<std::string> errs((size_t)n);
+    parallel_for(n, p->knobs.host_threads, [&](int i) {
+        char e[160] = "";
+        if (rd32(bufs[i]) != W || rd32(bufs[i] + 4) != H) { snprintf(e, sizeof e, "image is %ux%u, frame 0 is %ux%u", rd32(bufs[i]), rd32(bufs[i] + 4), W, H); counts[i] = -1; }
+        else counts[i] = rle_scan(bufs[i], lens[i], W, H, nullptr, 0, 0, e, sizeof e);
+        if (counts[i] < 0) errs[i] = e;
+    });
+    for (int i = 0; i < n; ++i)
+        if (counts[i] < 0) return fail(DH_EINVAL, "frame %d: %s", i, errs[i].c_str());
+    int rc = grow_pinned(&p->pin_begin, &p->pin_begin_cap, (size_t)n + 1);
+    if (rc) return rc;
+    p->pin_begin[0] = 0;
+    size_t nruns = 0;
+    for (int i = 0; i < n; ++i) { nruns += (size_t)counts[i]; if (nruns > 0xffffffffull) return fail(DH_ESIZE, "too many runs"); p->pin_begin[i + 1] = (uint32_t)nruns; }
+    rc = grow_pinned(&p->pin_blob, &p->pin_blob_cap, blob_off[n]);
+    if (rc == DH_OK) rc = grow_pinned(&p->pin_runs, &p->pin_runs_cap, std::max<size_t>(nruns, 1));
+    if (rc == DH_OK) rc = grow_device(&p->dev_blob, &p->dev_blob_cap, blob_off[n]);
+    if (rc == DH_OK) rc = grow_device(&p->dev_runs, &p->dev_runs_cap, std::max<size_t>(nruns, 1));
+    if (rc == DH_OK) rc = grow_device(&p->dev_begin, &p->dev_begin_cap, (size_t)n + 1);
+    if (rc) return rc;
+    // pass B: pack (the payload bytes as they are; the run table points into them)
+    parallel_for(n, p->knobs.host_threads, [&](int i) {
+        memcpy(p->pin_blob + blob_off[i], bufs[i], lens[i]);
+        char e[8];
+        (void)rle_scan(bufs[i], lens[i], W, H, p->pin_runs + p->pin_begin[i], (uint32_t)((size_t)i * W * H), (uint32_t)(blob_off[i] >> 1), e, sizeof e);
+    });
+    *W_ = W; *H_ = H;
+    return DH_OK;
+}
+
+// Uploads chunk [c0, c0 + cm) of the prepared batch on the copy stream and enqueues its decode into `frames_dev`
+// (frame c0 first) on stream s.
+static int rle_upload_decode(dh_predictor *p, const std::vector<size_t> &blob_off, int c0, int cm, int ci, uint32_t W, uint32_t H,
+                             uint16_t *frames_dev, hipStream_t s) {
+    hipStream_t cs = p->copy_stream;
+    const size_t b0 = blob_off[c0], b1 = blob_off[c0 + cm];
+    const uint32_t r0 = p->pin_begin[c0], r1 = p->pin_begin[c0 + cm];
+    HIP_TRY(hipMemcpyAsync(p->dev_blob + b0, p->pin_blob + b0, b1 - b0, hipMemcpyHostToDevice, cs));
+    if (r1 > r0) HIP_TRY(hipMemcpyAsync(p->dev_runs + r0, p->pin_runs + r0, (size_t)(r1 - r0) * sizeof(uint2), hipMemcpyHostToDevice, cs));
+    hipEvent_t ev = p->ev_stage[ci % DH_STAGE_EVENTS];
+    HIP_TRY(hipEventRecord(ev, cs));
+    HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+    HIP_TRY(hipMemsetAsync(frames_dev, 0, (size_t)cm * W * H * sizeof(uint16_t), s));          // the empty runs (biwi.rs:90-93)
+    RleArgs ra{};
+    ra.blob = (const uint16_t *)p->dev_blob; ra.runs = p->dev_runs; ra.run_begin = p->dev_begin + c0;
+    // the run table addresses pixels of the whole batch: frame c0 of the chunk is pixel c0 * W * H there
+    ra.frames = frames_dev - (size_t)c0 * W * H; ra.n_frames = cm;
+    const uint32_t per_frame = (r1 - r0 + (uint32_t)cm - 1) / (uint32_t)cm;
+    ra.blocks_per_frame = (int)std::max(1u, std::min(64u, (per_frame + 15) / 16));
+    HIP_TRY(dh_launch_rle_decode(ra, s));
+    return DH_OK;
+}
+
+extern "C" int dh_biwi_decode_depth_device(dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, uint16_t *frames_dev,
+                                           size_t cap_px, uint32_t *w, uint32_t *h) {
+    if (!p || !bufs || !lens || !w || !h) return fail(DH_EINVAL, "dh_biwi_decode_depth_device: NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->own_stream));             // the pinned staging buffers are free
+    HIP_TRY(hipStreamSynchronize(p->copy_stream));
+    std::vector<size_t> blob_off;
+    uint32_t W = 0, H = 0;
+    int rc = rle_prepare(p, bufs, lens, n, &W, &H, blob_off);
+    if (rc) return rc;
+    *w = W; *h = H;
+    if (!frames_dev) return DH_OK;                            // size query (validates as well)
+    if (cap_px < (size_t)n * W * H) return fail(DH_EINVAL, "output holds %zu pixels, the batch has %zu", cap_px, (size_t)n * W * H);
+    HIP_TRY(hipMemcpyAsync(p->dev_begin, p->pin_begin, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, p->own_stream));
+    const int chunk = std::min(n, p->knobs.stage_chunk * 2);
+    int ci = 0;
+    for (int c0 = 0; c0 < n; c0 += chunk, ++ci) {
+        const int cm = std::min(chunk, n - c0);
+        rc = rle_upload_decode(p, blob_off, c0, cm, ci, W, H, frames_dev + (size_t)c0 * W * H, p->own_stream);
+        if (rc) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamSynchronize(p->own_stream); return rc; }
+    }
+    HIP_TRY(hipStreamSynchronize(p->own_stream));
+    return DH_OK;
+}
+
+extern "C" int dh_predict_batch_rle(dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, const float K[9],
+                                    const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out) {
+    if (!p || !bufs || !lens || !K || !out) return fail(DH_EINVAL, "dh_predict_batch_rle: NULL argument");
+    if (n == 0) return DH_OK;
+    if (n < 0) return fail(DH_EINVAL, "negative batch size");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = p->own_stream;
+    const int slice = p->debug ? n : std::min(n, max_resident_frames(p));
+    for (int f0 = 0; f0 < n; f0 += slice) {
+        const int m = std::min(slice, n - f0);
+        HIP_TRY(hipStreamSynchronize(s));                         // pinned staging and device blob of the previous slice are free
+        HIP_TRY(hipStreamSynchronize(p->copy_stream));
+        std::vector<size_t> blob_off;
+        uint32_t W = 0, H = 0;
+        int rc = rle_prepare(p, bufs + f0, lens + f0, m, &W, &H, blob_off);   // validates: nothing launched on failure
         if (rc) return rc;
+        const int w = (int)W, h = (int)H;
+        rc = reserve(p, m, w, h);
+        if (rc == DH_OK) rc = ensure_frame_staging(p, (size_t)m * W * H * sizeof(uint16_t));
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(p->dev_begin, p->pin_begin, ((size_t)m + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        if (midp_guess) HIP_TRY(hipMemcpyAsync(p->ws_midp, midp_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+        if (rot_guess) HIP_TRY(hipMemcpyAsync(p->ws_rot, rot_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+        if (guess_mask) HIP_TRY(hipMemcpyAsync(p->ws_mask, guess_mask + f0, (size_t)m, hipMemcpyHostToDevice, s));
+        const int chunk = p->debug ? m : std::min(m, p->knobs.stage_chunk * 2);   // compressed chunks are small: twice the raw chunk
+        int ci = 0;
+        for (int c0 = 0; c0 < m; c0 += chunk, ++ci) {
+            const int cm = std::min(chunk, m - c0);
+            uint16_t *fr = p->ws_frames + (size_t)c0 * W * H;
+            rc = rle_upload_decode(p, blob_off, c0, cm, ci, W, H, fr, s);
+            if (rc == DH_OK)
+                rc = dh_predict_batch_device(p, fr, cm, w, h, K, midp_guess ? p->ws_midp + (size_t)c0 * 3 : nullptr,
+                                             rot_guess ? p->ws_rot + (size_t)c0 * 3 : nullptr, guess_mask ? p->ws_mask + c0 : nullptr, p->ws_poses + c0, s);
+            if (rc) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamSynchronize(s); return rc; }
+        }
         HIP_TRY(hipMemcpyAsync(out + f0, p->ws_poses, (size_t)m * sizeof(dh_pose), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
@@ -1001,10 +1287,10 @@ extern "C" int dh_hough_image_device(dh_predictor *p, const uint16_t *frames, in
     return DH_OK;
 }
 
-static int stage_frames(dh_predictor *p, const uint16_t *frames, int n, int w, int h) {
-    size_t fbytes = (size_t)n * w * h * sizeof(uint16_t);
+static int ensure_frame_staging(dh_predictor *p, size_t fbytes) {
     if (fbytes > p->ws_frames_bytes) {
         HIP_TRY(hipStreamSynchronize(p->own_stream));
+        HIP_TRY(hipStreamSynchronize(p->copy_stream));
         if (p->ws_frames) (void)hipFree(p->ws_frames);
         p->ws_frames = nullptr; p->ws_frames_bytes = 0;
         size_t want = fbytes;
@@ -1012,6 +1298,12 @@ static int stage_frames(dh_predictor *p, const uint16_t *frames, int n, int w, i
         if (rc) return rc;
         p->ws_frames_bytes = want;
     }
+    return DH_OK;
+}
+static int stage_frames(dh_predictor *p, const uint16_t *frames, int n, int w, int h) {
+    size_t fbytes = (size_t)n * w * h * sizeof(uint16_t);
+    int rc = ensure_frame_staging(p, fbytes);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(p->ws_frames, frames, fbytes, hipMemcpyHostToDevice, p->own_stream));
     return DH_OK;
 }

@@ -227,7 +227,17 @@ struct AuxArgs {
     uint32_t *hough32;       // 2-D Hough votes accumulated in 32 bits [n][h][w]
 };
 
+// k_rle_decode: BIWI run-length coded depth payloads -> frames (biwi.rs:81-103), see dh_kernels.hip
+struct RleArgs {
+    const uint16_t *blob;       // the uploaded payload bytes, viewed as u16 (every run's data sits at an even byte offset)
+    const uint2    *runs;       // per non-empty run: {first destination pixel in `frames`, index of its first value in `blob`}
+    const uint32_t *run_begin;  // [n_frames + 1] runs of frame i = [run_begin[i], run_begin[i + 1])
+    uint16_t       *frames;     // [n_frames][h][w], zero-filled before the launch
+    int n_frames, blocks_per_frame;
+};
+
 // launchers (dh_kernels.hip)
+hipError_t dh_launch_rle_decode(const RleArgs &a, hipStream_t s);
 hipError_t dh_launch_mask(const AuxArgs &a, hipStream_t s);
 hipError_t dh_launch_hough2d(const AuxArgs &a, uint16_t *out, hipStream_t s);
 hipError_t dh_kernels_init();

@@ -1862,3 +1862,31 @@ hipError_t dh_launch_hough2d(const AuxArgs &a, uint16_t *out, hipStream_t s) {
     hipLaunchKernelGGL(k_narrow_u16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.hough32, out, n);
     return hipGetLastError();
 }
+
+// ================================================================== k_rle_decode
+// Device side of read_depth (/root/reference src/db_reader/biwi.rs:81-103): the run-length coded depth payloads of a
+// frame batch have been uploaded as they are (one blob, every frame's bytes at a 16-byte aligned offset) together with
+// a run table the host built while validating the headers: per non-empty run its first destination pixel (index in
+// the batch's frame array) and the position of its first depth value in the blob (in u16 units; the run's length is
+// the u32 right in front of it, :94).  The frames are zero-filled by a memset (the empty runs, :90-93); here every
+// wave copies runs: lane i moves values i, i + 64, ... (:95-98).  Byte / index work only.
+#define RLE_THREADS 256
+__global__ void __launch_bounds__(RLE_THREADS) k_rle_decode(RleArgs a) {
+    const int frame = blockIdx.y, lane = threadIdx.x & (WAVE - 1);
+    const uint32_t r0 = a.run_begin[frame], r1 = a.run_begin[frame + 1];
+    const uint32_t wave = blockIdx.x * (RLE_THREADS / WAVE) + (threadIdx.x >> 6), nwaves = gridDim.x * (RLE_THREADS / WAVE);
+    for (uint32_t r = r0 + wave; r < r1; r += nwaves) {
+        const uint2 e = a.runs[r];                            // dst pixel, src u16 index
+        const uint32_t n_full = (uint32_t)a.blob[e.y - 2] | ((uint32_t)a.blob[e.y - 1] << 16);
+        const uint16_t *src = a.blob + e.y;
+        uint16_t *dst = a.frames + e.x;
+        for (uint32_t i = lane; i < n_full; i += WAVE) dst[i] = src[i];
+    }
+}
+
+hipError_t dh_launch_rle_decode(const RleArgs &a, hipStream_t s) {
+    if (a.n_frames == 0) return hipSuccess;
+    if (a.n_frames > 65535) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_rle_decode, dim3(a.blocks_per_frame, a.n_frames), dim3(RLE_THREADS), 0, s, a);
+    return hipGetLastError();
+}

@@ -145,6 +145,35 @@ class HoughPrediction:
                                          vp(rg), vp(gm), vp(out)))
         return out
 
+    @staticmethod
+    def _payload_arrays(payloads):
+        bufs = [np.frombuffer(b, dtype=np.uint8) for b in payloads]
+        ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * len(bufs))(*[b.size for b in bufs])
+        return bufs, ptrs, lens
+
+    def predict_batch_rle(self, payloads, intrinsic: IntrinsicMatrix, midp_guess=None, rot_guess=None, guess_mask=None) -> np.ndarray:
+        """Frames handed over as BIWI run-length coded depth payloads (the bytes of the `.bin` files,
+        biwi.rs:81-103): decoded on the device, then predicted.  -> POSE_DTYPE[n]."""
+        n = len(payloads)
+        bufs, ptrs, lens = self._payload_arrays(payloads)
+        K = np.ascontiguousarray(intrinsic.mat, dtype=np.float32).reshape(9)
+        mg = None if midp_guess is None else np.ascontiguousarray(midp_guess, dtype=np.float32).reshape(n, 3)
+        rg = None if rot_guess is None else np.ascontiguousarray(rot_guess, dtype=np.float64).reshape(n, 3)
+        gm = None if guess_mask is None else np.ascontiguousarray(guess_mask, dtype=np.uint8).reshape(n)
+        out = np.zeros(n, dtype=POSE_DTYPE)
+        check(self._lib.dh_predict_batch_rle(self._ph, ptrs, lens, C.c_int(n), vp(K), vp(mg), vp(rg), vp(gm), vp(out)))
+        return out
+
+    def decode_depth_device(self, payloads, frames_ptr: int | None = None, cap_px: int = 0) -> tuple[int, int]:
+        """BIWI payloads -> device frames at `frames_ptr` ([n][h][w] uint16); returns (w, h).  With
+        frames_ptr None only validates and reports the size."""
+        bufs, ptrs, lens = self._payload_arrays(payloads)
+        w, h = C.c_uint32(), C.c_uint32()
+        check(self._lib.dh_biwi_decode_depth_device(self._ph, ptrs, lens, C.c_int(len(payloads)), vp(frames_ptr), C.c_size_t(cap_px),
+                                                    C.byref(w), C.byref(h)))
+        return int(w.value), int(h.value)
+
     def predict_batch_device(self, frames_ptr: int, n: int, w: int, h: int, intrinsic: IntrinsicMatrix, out_ptr: int,
                              midp_guess_ptr: int | None = None, rot_guess_ptr: int | None = None,
                              guess_mask_ptr: int | None = None, stream: int = 0) -> None:

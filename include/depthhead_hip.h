@@ -139,10 +139,30 @@ int dh_predictor_sigma(const dh_predictor *p, float *out);
  * types.rs:10).  K: row-major 3x3 intrinsic (types.rs:405).  midp_guess (n*3 f32) / rot_guess
  * (n*3 f64, radians) are the Option<> arguments: NULL = None for every frame; guess_mask (n bytes,
  * may be NULL = all present) selects per frame: bit0 = midp_guess is Some, bit1 = rot_guess is
- * Some.  Synchronous: copies in, runs, copies out. */
+ * Some.  Synchronous: copies in, runs, copies out.  The upload is pipelined: frames cross PCIe in chunks while the
+ * kernels of the previous chunk run (without dh_debug_enable the parity taps then describe the LAST chunk only). */
 int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                      const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
                      dh_pose *out);
+
+/* Page-locked host memory for frame buffers (a camera driver or file reader writes frames there): dh_predict_batch
+ * then uploads by asynchronous DMA at PCIe speed, chunk k + 1 while the kernels of chunk k run.  Pageable buffers work
+ * too, more slowly (the runtime pins and unpins the pages of every copy). */
+int dh_host_alloc(size_t bytes, void **out);
+int dh_host_free(void *ptr);
+
+/* The same batch handed over as BIWI run-length coded depth payloads -- the bytes of the `.bin` files that
+ * db_reader::biwi::read_depth (src/db_reader/biwi.rs:81-103) parses: bufs[i] / lens[i] = payload of frame i; every
+ * frame must decode to the same w x h.  The host only walks the run headers (with the checks of dh_biwi_decode_depth:
+ * a truncated payload or a run that overruns the image gives DH_EINVAL BEFORE anything is launched); payloads and
+ * the run table cross PCIe instead of the 2-byte pixels (a BIWI frame is ~80 % background), the depth images are
+ * rebuilt on the device, byte for byte what dh_biwi_decode_depth yields, and predicted.  Synchronous. */
+int dh_predict_batch_rle(dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, const float K[9],
+                         const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out);
+/* The decode step alone: n payloads -> DEVICE frames [n][h][w] u16 (frames_dev == NULL: validate and return
+ * *w, *h only).  Synchronous (returns when the frames are in place). */
+int dh_biwi_decode_depth_device(dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n,
+                                uint16_t *frames_dev, size_t cap_px, uint32_t *w, uint32_t *h);
 
 /* Same with DEVICE pointers (frames, guesses, mask, out all device-resident) on `stream`
  * (a hipStream_t; NULL = default stream).  Asynchronous: returns after enqueueing; buffers must
