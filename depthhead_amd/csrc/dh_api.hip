@@ -318,6 +318,9 @@ struct dh_predictor {
     float *ws_midp = nullptr;
     double *ws_rot = nullptr;
     uint8_t *ws_mask = nullptr;
+    float *blur_kern = nullptr;      // device: gaussian_kernel_f32(gaussian_sigma) of the 2-D Hough variant, built on first use
+    int blur_klen = 0;
+    float blur_sigma = 0.0f;
     // leaf-id outputs for predict_mask / the 2-D Hough image, allocated on first use
     int32_t *aux_leaf = nullptr;
     uint8_t *aux_flags = nullptr;
@@ -423,6 +426,7 @@ extern "C" int dh_predictor_destroy(dh_predictor *p) {
     free_workspace(p);
     for (void *q : p->forest_allocs) (void)hipFree(q);
     if (p->kern_ord) (void)hipFree(p->kern_ord);
+    if (p->blur_kern) (void)hipFree(p->blur_kern);
     if (p->zeros) (void)hipFree(p->zeros);
     for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
@@ -1224,8 +1228,35 @@ static int aux_reserve(dh_predictor *p, int n, int w, int h, size_t out_bytes) {
     return DH_OK;
 }
 
+// imageproc 0.12.0 filter::gaussian_kernel_f32(sigma) (crate source not in the container; PARITY UNPINNED): radius
+// ceil(2 sigma), taps = the zero-mean normal density at 0, 1, ..., radius mirrored, NOT renormalised;
+// gaussian(x, r) = ((2.0 * PI).sqrt() * r).recip() * (-x.powi(2) / (2.0 * r.powi(2))).exp(), all in f32.
+static int blur_kernel(dh_predictor *p) {
+    const float sigma = p->params.gaussian_sigma;
+    if (p->blur_kern && p->blur_sigma == sigma) return DH_OK;
+    if (!(sigma > 0.0f)) return fail(DH_EINVAL, "gaussian_blur_f32 needs sigma > 0 (the reference asserts)");
+    const float r2 = ceilf(2.0f * sigma);
+    if (!(r2 <= 2048.0f)) return fail(DH_ESIZE, "blur radius %g too large", (double)r2);
+    const int radius = (int)r2;
+    std::vector<float> k((size_t)2 * radius + 1);
+    const float norm = 1.0f / (sqrtf(2.0f * 3.14159274101257324f) * sigma);
+    for (int i = 0; i <= radius; ++i) {
+        const float x = (float)i;
+        const float v = norm * expf(-(x * x) / (2.0f * (sigma * sigma)));
+        k[radius + i] = v; k[radius - i] = v;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (p->blur_kern) (void)hipFree(p->blur_kern);
+    p->blur_kern = nullptr;
+    int rc = dev_alloc(p, &p->blur_kern, k.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(p->blur_kern, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
+    p->blur_klen = (int)k.size(); p->blur_sigma = sigma;
+    return DH_OK;
+}
+
 static int aux_run(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint8_t *mask,
-                   uint16_t *hough, hipStream_t s) {
+                   uint16_t *hough, hipStream_t s, bool blur = false, dh_pose *poses2d = nullptr) {
     const Geom &g = p->geom;
     float kinv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, kid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (K) mat3_inv_f32(K, kinv);
@@ -1251,6 +1282,9 @@ static int aux_run(dh_predictor *p, const uint16_t *frames, int n, int w, int h,
         HIP_TRY(hipMemsetAsync(p->aux_u32, 0, (size_t)n * w * h * sizeof(uint32_t), s));
         a.hough32 = p->aux_u32;
         HIP_TRY(dh_launch_hough2d(a, hough, s));
+        // gaussian_blur_f32 (prediction.rs:844): horizontal pass into the (now free) 32-bit scratch, vertical pass back
+        if (blur) HIP_TRY(dh_launch_blur_u16(hough, (uint16_t *)p->aux_u32, hough, n, w, h, p->blur_kern, p->blur_klen, s));
+        if (poses2d) HIP_TRY(dh_launch_argmax2d(hough, frames, n, w, h, kinv, poses2d, s));
     }
     p->last_n = 0;   // the pose taps do not refer to this run
     return DH_OK;
@@ -1339,6 +1373,79 @@ extern "C" int dh_hough_image(dh_predictor *p, const uint16_t *frames, int n, in
         if (rc == DH_OK) rc = aux_run(p, p->ws_frames, m, w, h, K, nullptr, (uint16_t *)p->aux_out, p->own_stream);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(out + (size_t)f0 * w * h, p->aux_out, ob, hipMemcpyDeviceToHost, p->own_stream));
+        HIP_TRY(hipStreamSynchronize(p->own_stream));
+    }
+    return DH_OK;
+}
+
+// HoughPrediction::build_hough_image in full (prediction.rs:760-845) and predict_parameter_from2dhough (:343-367).
+static int hough2d_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *img_out,
+                          dh_pose *pose_out, hipStream_t s) {
+    DeviceGuard guard(p->device);
+    if (!guard.ok) return fail(DH_EHIP, "cannot select device %d", p->device);
+    int rc = blur_kernel(p);
+    if (rc) return rc;
+    const int slice = std::min(n, max_resident_frames(p));
+    for (int f0 = 0; f0 < n; f0 += slice) {
+        const int m = std::min(slice, n - f0);
+        const size_t ob = (size_t)m * w * h * sizeof(uint16_t);
+        rc = aux_reserve(p, m, w, h, img_out ? 0 : ob);       // no caller image: the blurred image lives in the scratch output
+        if (rc) return rc;
+        uint16_t *img = img_out ? img_out + (size_t)f0 * w * h : (uint16_t *)p->aux_out;
+        rc = aux_run(p, frames + (size_t)f0 * w * h, m, w, h, K, nullptr, img, s, true, pose_out ? pose_out + f0 : nullptr);
+        if (rc) return rc;
+    }
+    return DH_OK;
+}
+
+extern "C" int dh_build_hough_image_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                                           uint16_t *out, void *stream) {
+    if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_build_hough_image_device: NULL argument");
+    if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
+    return hough2d_device(p, frames, n, w, h, K, out, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int dh_predict_from2dhough_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                                             dh_pose *out, void *stream) {
+    if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_from2dhough_device: NULL argument");
+    if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
+    return hough2d_device(p, frames, n, w, h, K, nullptr, out, (hipStream_t)stream);
+}
+
+extern "C" int dh_build_hough_image(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *out) {
+    if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_build_hough_image: NULL argument");
+    if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = blur_kernel(p);
+    if (rc) return rc;
+    const int slice = std::min(n, max_resident_frames(p));
+    for (int f0 = 0; f0 < n; f0 += slice) {
+        const int m = std::min(slice, n - f0);
+        const size_t ob = (size_t)m * w * h * sizeof(uint16_t);
+        rc = aux_reserve(p, m, w, h, ob);
+        if (rc == DH_OK) rc = stage_frames(p, frames + (size_t)f0 * w * h, m, w, h);
+        if (rc == DH_OK) rc = aux_run(p, p->ws_frames, m, w, h, K, nullptr, (uint16_t *)p->aux_out, p->own_stream, true, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out + (size_t)f0 * w * h, p->aux_out, ob, hipMemcpyDeviceToHost, p->own_stream));
+        HIP_TRY(hipStreamSynchronize(p->own_stream));
+    }
+    return DH_OK;
+}
+
+extern "C" int dh_predict_from2dhough(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], dh_pose *out) {
+    if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_from2dhough: NULL argument");
+    if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = blur_kernel(p);
+    if (rc) return rc;
+    const int slice = std::min(n, max_resident_frames(p));
+    for (int f0 = 0; f0 < n; f0 += slice) {
+        const int m = std::min(slice, n - f0);
+        rc = aux_reserve(p, m, w, h, (size_t)m * w * h * sizeof(uint16_t));
+        if (rc == DH_OK) rc = stage_frames(p, frames + (size_t)f0 * w * h, m, w, h);
+        if (rc == DH_OK) rc = aux_run(p, p->ws_frames, m, w, h, K, nullptr, (uint16_t *)p->aux_out, p->own_stream, true, p->ws_poses);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out + f0, p->ws_poses, (size_t)m * sizeof(dh_pose), hipMemcpyDeviceToHost, p->own_stream));
         HIP_TRY(hipStreamSynchronize(p->own_stream));
     }
     return DH_OK;

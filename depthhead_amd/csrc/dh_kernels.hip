@@ -1890,3 +1890,85 @@ hipError_t dh_launch_rle_decode(const RleArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_rle_decode, dim3(a.blocks_per_frame, a.n_frames), dim3(RLE_THREADS), 0, s, a);
     return hipGetLastError();
 }
+
+// ================================================================== 2-D Hough variant: blur + argmax
+// imageproc::filter::gaussian_blur_f32 (imageproc 0.12.0, /root/reference Cargo.lock:555; called at
+// src/hough/prediction.rs:844) = separable_filter_equal(image, gaussian_kernel_f32(sigma)): a horizontal pass
+// writing a u16 image, then a vertical pass over that image.  Per output pixel: acc = 0; for every tap i in kernel
+// order acc = acc + (f32)pixel[clamped position] * kernel[i] (f32, multiply then add); result = Clamp<f32> for u16
+// (x >= 65535 -> 65535, x <= 0 -> 0, else truncation).  Image borders replicate the edge pixel.
+// PARITY UNPINNED: the crate's source is not in the container; this restates its published algorithm.
+#define BLUR_TILE 256
+template <bool VERT>
+__global__ void __launch_bounds__(BLUR_TILE) k_blur_u16(const uint16_t *in, uint16_t *out, int w, int h, const float *kern, int klen) {
+    const int frame = blockIdx.z;
+    const size_t fo = (size_t)frame * w * h;
+    const int x = VERT ? (int)(blockIdx.x * BLUR_TILE + threadIdx.x) : (int)(blockIdx.x * BLUR_TILE + threadIdx.x);
+    const int y = (int)blockIdx.y;
+    if (x >= w) return;
+    const int half = klen / 2;
+    float acc = 0.0f;
+    if (VERT) {
+        for (int i = 0; i < klen; ++i) {
+            const int yy = min(max(y + i - half, 0), h - 1);
+            acc = __fadd_rn(acc, __fmul_rn((float)in[fo + (size_t)yy * w + x], kern[i]));
+        }
+    } else {
+        const uint16_t *row = in + fo + (size_t)y * w;
+        for (int i = 0; i < klen; ++i) {
+            const int xx = min(max(x + i - half, 0), w - 1);
+            acc = __fadd_rn(acc, __fmul_rn((float)row[xx], kern[i]));
+        }
+    }
+    uint16_t r;
+    if (acc < 65535.0f) r = acc > 0.0f ? (uint16_t)acc : (uint16_t)0;      // Clamp<f32> for u16; NaN -> 65535 like the crate's comparison chain
+    else r = 65535;
+    out[fo + (size_t)y * w + x] = r;
+}
+
+hipError_t dh_launch_blur_u16(const uint16_t *in, uint16_t *tmp, uint16_t *out, int n, int w, int h, const float *kern, int klen, hipStream_t s) {
+    if (n == 0 || w == 0 || h == 0) return hipSuccess;
+    if (h > 65535 || n > 65535) return hipErrorInvalidConfiguration;
+    const dim3 grid((w + BLUR_TILE - 1) / BLUR_TILE, h, n);
+    hipLaunchKernelGGL(k_blur_u16<false>, grid, dim3(BLUR_TILE), 0, s, in, tmp, w, h, kern, klen);
+    hipLaunchKernelGGL(k_blur_u16<true>, grid, dim3(BLUR_TILE), 0, s, (const uint16_t *)tmp, out, w, h, kern, klen);
+    return hipGetLastError();
+}
+
+// HoughPrediction::predict_parameter_from2dhough (prediction.rs:343-367): `max_by_key` over the pixel indices returns
+// the LAST index holding the greatest value; the head position is that pixel lifted with the frame's depth there.
+__global__ void __launch_bounds__(1024) k_argmax2d(const uint16_t *hough, const uint16_t *frames, int w, int h, Mat3Arg kinv, dh_pose *out) {
+    __shared__ unsigned long long red[16];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const size_t fo = (size_t)frame * w * h;
+    const uint32_t npx = (uint32_t)w * (uint32_t)h;
+    unsigned long long best = 0;                                           // (value << 32) | index: greatest value, then greatest index
+    for (uint32_t i = tid; i < npx; i += 1024) {
+        const unsigned long long k = ((unsigned long long)hough[fo + i] << 32) | i;
+        if (k >= best) best = k;
+    }
+    for (int d = WAVE / 2; d; d >>= 1) { const unsigned long long o = __shfl_down(best, d); if (o > best) best = o; }
+    if ((tid & (WAVE - 1)) == 0) red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 16; ++i) if (red[i] > best) best = red[i];
+        const uint32_t idx = (uint32_t)best;
+        const uint32_t x = idx % (uint32_t)w, y = idx / (uint32_t)w;       // :357-358
+        const uint16_t z = frames[fo + idx];                               // :359
+        float p[3];
+        to3d(kinv.m, (float)x, (float)y, (float)z, p);                     // :360
+        dh_pose r;
+        r.mid_point[0] = p[0]; r.mid_point[1] = p[1]; r.mid_point[2] = p[2];
+        r.reserved = 0;
+        r.rotation[0] = 0.0; r.rotation[1] = 0.0; r.rotation[2] = 0.0;     // :363
+        out[frame] = r;
+    }
+}
+
+hipError_t dh_launch_argmax2d(const uint16_t *hough, const uint16_t *frames, int n, int w, int h, const float kinv[9], dh_pose *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    Mat3Arg k;
+    for (int i = 0; i < 9; ++i) k.m[i] = kinv[i];
+    hipLaunchKernelGGL(k_argmax2d, dim3(n), dim3(1024), 0, s, hough, frames, w, h, k, out);
+    return hipGetLastError();
+}

@@ -210,6 +210,32 @@ class HoughPrediction:
         check(self._lib.dh_hough_image(self._ph, vp(frames), C.c_int(n), C.c_int(w), C.c_int(h), vp(K), vp(out)))
         return out[0] if single else out
 
+    def build_hough_image(self, img, intrinsic: IntrinsicMatrix) -> np.ndarray:
+        """prediction.rs:760-845 in full: the votes blurred by imageproc's gaussian_blur_f32(sigma = gaussian_sigma)
+        (external crate, restated from its published algorithm: parity unpinned)."""
+        frames = np.ascontiguousarray(img, dtype=np.uint16)
+        single = frames.ndim == 2
+        if single:
+            frames = frames[None]
+        n, h, w = frames.shape
+        K = np.ascontiguousarray(intrinsic.mat, dtype=np.float32).reshape(9)
+        out = np.zeros((n, h, w), dtype=np.uint16)
+        check(self._lib.dh_build_hough_image(self._ph, vp(frames), C.c_int(n), C.c_int(w), C.c_int(h), vp(K), vp(out)))
+        return out[0] if single else out
+
+    def predict_parameter_from2dhough(self, img, intrinsic: IntrinsicMatrix):
+        """prediction.rs:343-367: head position from the argmax of the blurred 2-D Hough image; rotation is always
+        zero there.  One frame -> PredictionResult, a batch [n, H, W] -> POSE_DTYPE[n]."""
+        frames = np.ascontiguousarray(img, dtype=np.uint16)
+        single = frames.ndim == 2
+        if single:
+            frames = frames[None]
+        n, h, w = frames.shape
+        K = np.ascontiguousarray(intrinsic.mat, dtype=np.float32).reshape(9)
+        out = np.zeros(n, dtype=POSE_DTYPE)
+        check(self._lib.dh_predict_from2dhough(self._ph, vp(frames), C.c_int(n), C.c_int(w), C.c_int(h), vp(K), vp(out)))
+        return PredictionResult(out["mid_point"][0].copy(), out["rotation"][0].copy()) if single else out
+
     def graph_capture(self, frames_ptr: int, n: int, w: int, h: int, intrinsic: IntrinsicMatrix, out_ptr: int,
                       midp_guess_ptr: int | None = None, rot_guess_ptr: int | None = None,
                       guess_mask_ptr: int | None = None) -> None:

@@ -181,13 +181,27 @@ int dh_predict_mask_device(dh_predictor *p, const uint16_t *frames, int n, int w
                            void *stream);
 /* The VOTING stage of HoughPrediction::build_hough_image (prediction.rs:760-840): every leaf with
  * prob >= 0.95 casts (255 * prob) / n_offsets at the projected vote pixel, u16 wrapping.  out is
- * n*h*w u16, the image the reference then passes to imageproc::filter::gaussian_blur_f32 (:844) --
- * that external blur (and the argmax of predict_parameter_from2dhough, :343-367) is left to the
- * caller. */
+ * n*h*w u16, the image the reference then passes to imageproc::filter::gaussian_blur_f32 (:844):
+ * dh_build_hough_image below adds that blur, dh_predict_from2dhough the argmax of :343-367. */
 int dh_hough_image(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                    uint16_t *out);
 int dh_hough_image_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                           uint16_t *out, void *stream);
+
+/* HoughPrediction::build_hough_image IN FULL (prediction.rs:760-845): the votes above passed through
+ * imageproc::filter::gaussian_blur_f32(_, gaussian_sigma) (:844) -- a separable Gaussian with taps at 0..ceil(2 sigma),
+ * f32 accumulation in tap order, each pass clamped and truncated to u16, image borders replicated.  imageproc 0.12.0
+ * (Cargo.lock:555) is an external crate whose source is not vendored: PARITY UNPINNED, the blur restates the crate's
+ * published algorithm (see oracle/dh_oracle.c orc_gaussian_blur_u16).  Needs gaussian_sigma > 0 (the crate asserts). */
+int dh_build_hough_image(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *out);
+int dh_build_hough_image_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                                uint16_t *out, void *stream);
+/* HoughPrediction::predict_parameter_from2dhough (prediction.rs:343-367): argmax of that image -- `max_by_key`
+ * keeps the LAST of equal maxima -- lifted to 3-D with the frame's depth at that pixel (img_to_space_coord);
+ * rotation is always (0, 0, 0) there (:363). */
+int dh_predict_from2dhough(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], dh_pose *out);
+int dh_predict_from2dhough_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+                                  dh_pose *out, void *stream);
 
 /* hipGraph path for launch-bound use (single frames, small frames): capture ONE
  * dh_predict_batch_device call -- device pointers, sizes and K are baked in -- then replay it with one

@@ -575,6 +575,110 @@ int orc_hough_image(const orc_forest *f, const orc_model *m, const uint16_t *img
     return 0;
 }
 
+/* ---- imageproc 0.12.0 filter::gaussian_blur_f32 (external crate, /root/reference Cargo.toml:26, Cargo.lock:555-, call at
+ * src/hough/prediction.rs:844).  ITS SOURCE IS NOT IN THE CONTAINER: this restates the crate's published algorithm --
+ * PARITY UNPINNED.
+ *   gaussian_blur_f32(image, sigma): assert!(sigma > 0.0); separable_filter_equal(image, &gaussian_kernel_f32(sigma))
+ *   gaussian_kernel_f32: kernel_radius = (2.0 * sigma).ceil() as usize; data[radius +- i] = gaussian(i as f32, sigma),
+ *       i = 0..=radius (the kernel is NOT renormalised)
+ *   gaussian(x, r) = ((2.0 * PI).sqrt() * r).recip() * (-x.powi(2) / (2.0 * r.powi(2))).exp()          (all f32)
+ *   separable_filter: horizontal_filter -> an image of the SAME pixel type (u16), then vertical_filter over that;
+ *       per output pixel: acc = 0; for (i, k) in kernel.enumerate(): p = clamp(pos + i - len/2, 0, side-1);
+ *       acc = acc + (pixel as f32) * k;   result = <u16 as Clamp<f32>>::clamp(acc):
+ *       if x < 65535.0 { if x > 0.0 { x as u16 } else { 0 } } else { 65535 }                                */
+static uint16_t clamp_f32_u16(float x) {
+    if (x < 65535.0f) return x > 0.0f ? (uint16_t)x : (uint16_t)0;
+    return 65535;
+}
+
+int orc_gaussian_kernel_f32(float sigma, float *out, uint32_t cap, uint32_t *len) {
+    if (!(sigma > 0.0f) || !len) return -1;                              /* assert!(sigma > 0.0) */
+    float r2 = ceilf(2.0f * sigma);
+    if (!(r2 <= 1.0e6f)) return -1;
+    uint32_t radius = (uint32_t)r2;
+    *len = 2 * radius + 1;
+    if (!out) return 0;
+    if (cap < *len) return -1;
+    const float pi = 3.14159274101257324f;                               /* std::f32::consts::PI */
+    const float norm = 1.0f / (sqrtf(2.0f * pi) * sigma);                /* ((2.0 * PI).sqrt() * r).recip() */
+    for (uint32_t i = 0; i <= radius; ++i) {
+        float x = (float)i;
+        float v = norm * expf(-(x * x) / (2.0f * (sigma * sigma)));
+        out[radius + i] = v;
+        out[radius - i] = v;
+    }
+    return 0;
+}
+
+int orc_gaussian_blur_u16(const uint16_t *in, uint32_t w, uint32_t h, float sigma, uint16_t *out) {
+    uint32_t klen = 0;
+    if (!in || !out || orc_gaussian_kernel_f32(sigma, NULL, 0, &klen)) return -1;
+    if (w == 0 || h == 0) return 0;
+    float *k = (float *)malloc((size_t)klen * sizeof(float));
+    uint16_t *tmp = (uint16_t *)malloc((size_t)w * h * sizeof(uint16_t));
+    if (!k || !tmp) { free(k); free(tmp); return -2; }
+    orc_gaussian_kernel_f32(sigma, k, klen, &klen);
+    const int64_t half = (int64_t)(klen / 2);
+    for (uint32_t y = 0; y < h; ++y)                                      /* horizontal_filter */
+        for (uint32_t x = 0; x < w; ++x) {
+            float acc = 0.0f;
+            for (uint32_t i = 0; i < klen; ++i) {
+                int64_t xp = (int64_t)x + (int64_t)i - half;
+                if (xp < 0) xp = 0;
+                if (xp > (int64_t)w - 1) xp = (int64_t)w - 1;
+                acc = acc + (float)in[(size_t)y * w + (size_t)xp] * k[i];
+            }
+            tmp[(size_t)y * w + x] = clamp_f32_u16(acc);
+        }
+    for (uint32_t y = 0; y < h; ++y)                                      /* vertical_filter */
+        for (uint32_t x = 0; x < w; ++x) {
+            float acc = 0.0f;
+            for (uint32_t i = 0; i < klen; ++i) {
+                int64_t yp = (int64_t)y + (int64_t)i - half;
+                if (yp < 0) yp = 0;
+                if (yp > (int64_t)h - 1) yp = (int64_t)h - 1;
+                acc = acc + (float)tmp[(size_t)yp * w + x] * k[i];
+            }
+            out[(size_t)y * w + x] = clamp_f32_u16(acc);
+        }
+    free(k); free(tmp);
+    return 0;
+}
+
+/* HoughPrediction::build_hough_image in full (prediction.rs:760-845): votes (:760-840) + blur (:844). */
+int orc_build_hough_image(const orc_forest *f, const orc_model *m, const uint16_t *img, uint32_t w, uint32_t h,
+                          const float K[9], int rect_mode, uint16_t *out) {
+    uint16_t *votes = (uint16_t *)malloc((size_t)w * h * sizeof(uint16_t));
+    if (!votes) return -2;
+    int rc = orc_hough_image(f, m, img, w, h, K, rect_mode, votes);
+    if (rc == 0) rc = orc_gaussian_blur_u16(votes, w, h, m->gaussian_sigma, out);          /* :844 */
+    free(votes);
+    return rc;
+}
+
+/* HoughPrediction::predict_parameter_from2dhough (prediction.rs:343-367). */
+int orc_predict_from2dhough(const orc_forest *f, const orc_model *m, const uint16_t *img, uint32_t w, uint32_t h,
+                            const float K[9], int rect_mode, orc_pose *out) {
+    if (!out) return -1;
+    uint16_t *hough = (uint16_t *)malloc((size_t)w * h * sizeof(uint16_t));
+    if (!hough) return -2;
+    int rc = orc_build_hough_image(f, m, img, w, h, K, rect_mode, hough);                  /* :348 */
+    if (rc) { free(hough); return rc; }
+    /* (0..w*h).max_by_key(|i| hough[(i % w, i / w)]): Iterator::max_by_key returns the LAST maximal element (:351-356) */
+    uint32_t best = 0;
+    for (uint32_t i = 0; i < w * h; ++i)
+        if (hough[i] >= hough[best]) best = i;
+    uint32_t x = best % w, y = best / w;                                                   /* :357-358 */
+    uint16_t z = img[(size_t)y * w + x];                                                   /* :359 */
+    float Kinv[9], p[3];
+    inv3_f32(K, Kinv);
+    to3d(Kinv, (float)x, (float)y, (float)z, p);                                           /* :360 */
+    memset(out, 0, sizeof *out);
+    out->mid_point[0] = p[0]; out->mid_point[1] = p[1]; out->mid_point[2] = p[2];           /* :361-365 */
+    free(hough);
+    return 0;
+}
+
 int orc_predict_batch(const orc_forest *f, const orc_model *m, const uint16_t *imgs, uint32_t n,
                       uint32_t w, uint32_t h, const float K[9], const float *midp_guess,
                       const double *rot_guess, int rect_mode, int threads, orc_pose *out) {

@@ -118,9 +118,19 @@ int orc_predict_batch(const orc_forest *f, const orc_model *m, const uint16_t *i
 int orc_predict_mask(const orc_forest *f, const orc_model *m, const uint16_t *img, uint32_t w, uint32_t h,
                      int rect_mode, uint8_t *mask);
 /* The voting stage of HoughPrediction::build_hough_image (prediction.rs:760-840), i.e. the u16 image
- * BEFORE imageproc's gaussian_blur_f32 (:844; external crate, not restated).  out: w*h u16. */
+ * BEFORE imageproc's gaussian_blur_f32 (:844; see orc_build_hough_image).  out: w*h u16. */
 int orc_hough_image(const orc_forest *f, const orc_model *m, const uint16_t *img, uint32_t w, uint32_t h,
                     const float K[9], int rect_mode, uint16_t *out);
+
+/* imageproc 0.12.0 filter::gaussian_blur_f32 on a u16 image (external crate, source NOT in the container: restated from
+ * its published algorithm, PARITY UNPINNED -- details in dh_oracle.c).  out: w*h u16. */
+int orc_gaussian_kernel_f32(float sigma, float *out, uint32_t cap, uint32_t *len);
+int orc_gaussian_blur_u16(const uint16_t *in, uint32_t w, uint32_t h, float sigma, uint16_t *out);
+/* HoughPrediction::build_hough_image in full (prediction.rs:760-845) and predict_parameter_from2dhough (:343-367). */
+int orc_build_hough_image(const orc_forest *f, const orc_model *m, const uint16_t *img, uint32_t w, uint32_t h,
+                          const float K[9], int rect_mode, uint16_t *out);
+int orc_predict_from2dhough(const orc_forest *f, const orc_model *m, const uint16_t *img, uint32_t w, uint32_t h,
+                            const float K[9], int rect_mode, orc_pose *out);
 
 /* ---- helpers exported for the known-answer tests ---- */
 void   orc_mat3_inv_f64(const double m[9], double out[9]);        /* meancov_estimation.rs:344-352 */

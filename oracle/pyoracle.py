@@ -193,3 +193,49 @@ def hough_image(forest, model, img: np.ndarray, K: np.ndarray, rect_mode: int = 
     if rc != 0:
         raise ValueError(f"orc_hough_image failed: {rc}")
     return out
+
+
+def gaussian_kernel(sigma: float) -> np.ndarray:
+    """imageproc 0.12.0 filter::gaussian_kernel_f32 (restated; parity unpinned)."""
+    n = C.c_uint32()
+    if lib().orc_gaussian_kernel_f32(C.c_float(sigma), None, C.c_uint32(0), C.byref(n)) != 0:
+        raise ValueError("sigma must be > 0")
+    out = np.zeros(n.value, dtype=np.float32)
+    lib().orc_gaussian_kernel_f32(C.c_float(sigma), _p(out), C.c_uint32(out.size), C.byref(n))
+    return out
+
+
+def gaussian_blur_u16(img: np.ndarray, sigma: float) -> np.ndarray:
+    """imageproc 0.12.0 filter::gaussian_blur_f32 on a u16 image (restated; parity unpinned)."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    out = np.zeros((h, w), dtype=np.uint16)
+    if lib().orc_gaussian_blur_u16(_p(img), C.c_uint32(w), C.c_uint32(h), C.c_float(sigma), _p(out)) != 0:
+        raise ValueError("orc_gaussian_blur_u16 failed")
+    return out
+
+
+def build_hough_image(forest, model, img: np.ndarray, K: np.ndarray, rect_mode: int = RECT_SAT) -> np.ndarray:
+    """HoughPrediction::build_hough_image in full (prediction.rs:760-845)."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+    fs, ms = _forest_struct(forest), _model_struct(model)
+    out = np.zeros((h, w), dtype=np.uint16)
+    rc = lib().orc_build_hough_image(C.byref(fs), C.byref(ms), _p(img), C.c_uint32(w), C.c_uint32(h), _p(K), C.c_int(rect_mode), _p(out))
+    if rc != 0:
+        raise ValueError(f"orc_build_hough_image failed: {rc}")
+    return out
+
+
+def predict_from2dhough(forest, model, img: np.ndarray, K: np.ndarray, rect_mode: int = RECT_SAT):
+    """HoughPrediction::predict_parameter_from2dhough (prediction.rs:343-367) -> (mid_point f32[3], rotation f64[3])."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+    fs, ms = _forest_struct(forest), _model_struct(model)
+    out = np.zeros(1, dtype=POSE_DTYPE)
+    rc = lib().orc_predict_from2dhough(C.byref(fs), C.byref(ms), _p(img), C.c_uint32(w), C.c_uint32(h), _p(K), C.c_int(rect_mode), _p(out))
+    if rc != 0:
+        raise ValueError(f"orc_predict_from2dhough failed: {rc}")
+    return out["mid_point"][0].copy(), out["rotation"][0].copy()
