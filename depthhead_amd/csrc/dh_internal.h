@@ -15,6 +15,7 @@
 #define LF_PROB 1u   // prob > 0.0                      (prediction.rs:590)
 #define LF_ROT 2u    // trace(cov(rotations)) <= 400.0  (prediction.rs:600)
 #define LF_OFF 4u    // trace(cov(offsets))  <= 5200.0  (prediction.rs:643)
+#define LF_FIN 8u    // every offset vote of the leaf is finite and below 1e30 in magnitude (k_vote's pinhole fast path relies on it)
 
 // Everything k_traverse needs to turn (patch, leaf) into its three hit records: 4 x 16-byte loads.
 struct __attribute__((aligned(16))) LeafTpl {

@@ -142,6 +142,9 @@ __global__ void __launch_bounds__(256) k_leaf_prepare(DevForest f) {
                 }
             if (!finite)
                 for (int k = 0; k < 3; ++k) { omin[k] = -INFINITY; omax[k] = INFINITY; }
+            bool small = finite;
+            for (int k = 0; k < 3; ++k) small = small && omin[k] > -1.0e30f && omax[k] < 1.0e30f;
+            if (small) flags |= LF_FIN;
         }
     }
     // ---- rotation bins (:605-632); host validation guarantees [0,120) for leaves that can vote.
@@ -1278,7 +1281,58 @@ hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream
 #define VOTE_ILP 12              // offset votes a lane keeps in flight (4 lanes x 12 = a 48-vote leaf in one round)
 #endif
 
-template <bool TAB>
+// Position votes of one hit record into the workgroup's 20 x 20 grid (prediction.rs:647-676): lane `sub` of the VOTE_SUB
+// lanes sharing the record takes the leaf's votes sub, sub + VOTE_SUB, ...  PINNED: pinhole form of the projection (k_vote).
+template <bool TAB, bool PINNED>
+__device__ __forceinline__ void vote_positions(const VoteArgs &a, uint32_t *pos, const uint8_t *gxt, const uint8_t *gyt, const float4 rec,
+                                               uint32_t v, uint32_t fc, uint32_t sub, float wm1, float hm1) {
+    const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
+    uint32_t last = 0xFFFFFFFFu, acc = 0;      // neighbouring votes mostly share a cell: one atomic per run
+    for (uint32_t o0 = ob + sub; o0 < oe; o0 += VOTE_SUB * VOTE_ILP) {   // the lane's next VOTE_ILP votes: loads first
+        float ox[VOTE_ILP], oy[VOTE_ILP], oz[VOTE_ILP];
+#pragma unroll
+        for (int j = 0; j < VOTE_ILP; ++j) {
+            const uint32_t o = min(o0 + VOTE_SUB * j, oe - 1);
+            const float4 of = a.f.off4[o];                          // 4 lanes x 16 B = one 64-byte line per record group
+            ox[j] = of.x; oy[j] = of.y; oz[j] = of.z;
+        }
+#pragma unroll
+        for (int j = 0; j < VOTE_ILP; ++j) {
+            if (o0 + VOTE_SUB * j >= oe) break;
+            float nx = __fsub_rn(rec.x, ox[j]), ny = __fsub_rn(rec.y, oy[j]), nz = __fsub_rn(rec.z, oz[j]); // :647
+            if (nz < 0.0f) continue;                                              // :650
+            float r[3];
+            if (PINNED) {
+                r[0] = __fadd_rn(__fmul_rn(nx, a.k[0]), __fmul_rn(nz, a.k[2]));
+                r[1] = __fadd_rn(__fmul_rn(ny, a.k[4]), __fmul_rn(nz, a.k[5]));
+                r[2] = __fadd_rn(nz, 0.0f);                                       // (x * 0 + y * 0) + z * 1: -0 becomes +0
+            } else {
+                matvec3(a.k, nx, ny, nz, r);                                      // types.rs:425
+            }
+            float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
+            float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;           // :662
+            float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;           // :663
+            // x2 in [0, w-1] and never NaN after the clamps: `as usize` is a plain truncation
+            const uint32_t xi = (uint32_t)x2, yi = (uint32_t)y2;
+            const uint32_t gx = TAB ? gxt[xi] : xi * DH_GRID / (uint32_t)a.w;      // :671-672
+            const uint32_t gy = TAB ? gyt[yi] : yi * DH_GRID / (uint32_t)a.h;
+            const uint32_t idx = gy * DH_GRID + gx;
+            if (idx != last) {
+                if (acc) atomicAdd(&pos[last], acc);                              // :675
+                last = idx; acc = 0;
+            }
+            acc += v;
+        }
+    }
+    if (acc) atomicAdd(&pos[last], acc);
+}
+
+// PIN: the intrinsic matrix has the pinhole form [[fx, 0, cx], [0, fy, cy], [0, 0, 1]] (types.rs:418-420 and every BIWI
+// calibration): of the nine products of space_to_img_coord's matrix-vector product (types.rs:425, meancov_estimation.rs:201-216)
+// five are x * 0 or z * 1.  For finite operands they are exact no-ops -- a + (+-0) = a, and the sign of a zero sum only
+// matters for r2, restored by adding +0 -- so four products and three sums give bit-identical r.  Hits whose window centre or
+// leaf offsets are not finite and small (LF_FIN) take the general expression (there 0 * inf = NaN must propagate).
+template <bool TAB, bool PIN>
 __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
     __shared__ uint32_t pos[DH_POSGRID];
     __shared__ uint32_t rot[DH_GRID3];
@@ -1304,47 +1358,28 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
     // VOTE_SUB lanes share one hit record: lane `sub` takes the leaf's votes sub, sub + VOTE_SUB, ... so the
     // chain of dependent offset loads per lane is n_votes / VOTE_SUB long and all lanes of the workgroup stay busy
     const uint32_t sub = tid & (VOTE_SUB - 1u);
-    for (uint32_t i = h0 + tid / VOTE_SUB; i < h1; i += VOTE_THREADS / VOTE_SUB) {
-        const float4 rec = *(const float4 *)(hits + i);
-        const int4 b1 = ((const int4 *)(box + i))[1];
+    // the records of a lane's NEXT hit are requested before the current one is worked on: a hit then costs one dependent
+    // round trip (its offset votes) instead of two
+    const uint32_t i_first = h0 + tid / VOTE_SUB;
+    float4 rec_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 b1_n = make_int4(0, 0, 0, 0);
+    if (i_first < h1) { rec_n = *(const float4 *)(hits + i_first); b1_n = ((const int4 *)(box + i_first))[1]; }
+    for (uint32_t i = i_first; i < h1; i += VOTE_THREADS / VOTE_SUB) {
+        const float4 rec = rec_n;
+        const int4 b1 = b1_n;
+        const uint32_t i_next = i + VOTE_THREADS / VOTE_SUB;
+        if (i_next < h1) { rec_n = *(const float4 *)(hits + i_next); b1_n = ((const int4 *)(box + i_next))[1]; }
         const uint4 rr = a.leaf_hits ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4 *)(hr + i);   // rotation cells: only without the leaf histogram
         const uint32_t v = (uint32_t)b1.z, fc = (uint32_t)b1.w;
         if ((fc & LF_ROT) && !a.leaf_hits)
             for (uint32_t r = rr.z + sub; r < rr.z + (rr.w >> 16); r += VOTE_SUB) atomicAdd(&rot[a.f.rot_rough[r]], v * a.f.rough_mult[r]);   // :636
+        // the pinhole form of the projection is taken by whole waves (a wave with one hit whose operands are not finite and
+        // small takes the general expression for all of its hits: a uniform branch, not a per-lane select of both results)
+        const bool pin_lane = PIN && (fc & LF_FIN) && fabsf(rec.x) < 1.0e30f && fabsf(rec.y) < 1.0e30f && fabsf(rec.z) < 1.0e30f;
+        const bool pin_wave = PIN && __ballot((fc & LF_OFF) && !pin_lane) == 0ull;
         if (fc & LF_OFF) {
-            const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
-            uint32_t last = 0xFFFFFFFFu, acc = 0;      // neighbouring votes mostly share a cell: one atomic per run
-            for (uint32_t o0 = ob + sub; o0 < oe; o0 += VOTE_SUB * VOTE_ILP) {   // the lane's next VOTE_ILP votes: loads first
-                float ox[VOTE_ILP], oy[VOTE_ILP], oz[VOTE_ILP];
-#pragma unroll
-                for (int j = 0; j < VOTE_ILP; ++j) {
-                    const uint32_t o = min(o0 + VOTE_SUB * j, oe - 1);
-                    const float4 of = a.f.off4[o];                          // 4 lanes x 16 B = one 64-byte line per record group
-                    ox[j] = of.x; oy[j] = of.y; oz[j] = of.z;
-                }
-#pragma unroll
-                for (int j = 0; j < VOTE_ILP; ++j) {
-                    if (o0 + VOTE_SUB * j >= oe) break;
-                    float nx = __fsub_rn(rec.x, ox[j]), ny = __fsub_rn(rec.y, oy[j]), nz = __fsub_rn(rec.z, oz[j]); // :647
-                    if (nz < 0.0f) continue;                                              // :650
-                    float r[3];
-                    matvec3(a.k, nx, ny, nz, r);                                          // types.rs:425
-                    float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
-                    float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;           // :662
-                    float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;           // :663
-                    // x2 in [0, w-1] and never NaN after the clamps: `as usize` is a plain truncation
-                    const uint32_t xi = (uint32_t)x2, yi = (uint32_t)y2;
-                    const uint32_t gx = TAB ? gxt[xi] : xi * DH_GRID / (uint32_t)a.w;      // :671-672
-                    const uint32_t gy = TAB ? gyt[yi] : yi * DH_GRID / (uint32_t)a.h;
-                    const uint32_t idx = gy * DH_GRID + gx;
-                    if (idx != last) {
-                        if (acc) atomicAdd(&pos[last], acc);                              // :675
-                        last = idx; acc = 0;
-                    }
-                    acc += v;
-                }
-            }
-            if (acc) atomicAdd(&pos[last], acc);
+            if (pin_wave) vote_positions<TAB, true>(a, pos, gxt, gyt, rec, v, fc, sub, wm1, hm1);
+            else vote_positions<TAB, false>(a, pos, gxt, gyt, rec, v, fc, sub, wm1, hm1);
         }
     }
     if (KNOB_STOP(a.stop == 2)) return;
@@ -1372,8 +1407,15 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
 
 hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
     if (a.n_frames == 0) return hipSuccess;
-    if (a.w <= VOTE_TAB && a.h <= VOTE_TAB) hipLaunchKernelGGL(k_vote<true>, dim3(VOTE_SLICES, a.n_frames), dim3(VOTE_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(k_vote<false>, dim3(VOTE_SLICES, a.n_frames), dim3(VOTE_THREADS), 0, s, a);
+    const bool pin = a.k[1] == 0.0f && a.k[3] == 0.0f && a.k[6] == 0.0f && a.k[7] == 0.0f && a.k[8] == 1.0f;
+    const dim3 grid(VOTE_SLICES, a.n_frames), block(VOTE_THREADS);
+    if (a.w <= VOTE_TAB && a.h <= VOTE_TAB) {
+        if (pin) hipLaunchKernelGGL((k_vote<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_vote<true, false>), grid, block, 0, s, a);
+    } else {
+        if (pin) hipLaunchKernelGGL((k_vote<false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_vote<false, false>), grid, block, 0, s, a);
+    }
     return hipGetLastError();
 }
 

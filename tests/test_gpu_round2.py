@@ -360,3 +360,31 @@ def test_two_rank_bench_rehearsal_on_one_gpu(oracle, hip_lib, tmp_path):
         frames = synth.biwi_batch(nf, w, h, first=rank * nf)          # bench.py's frames of that rank
         ref = oracle.predict_batch(forest, model, frames, K)
         assert _poses_equal(got[rank * nf:(rank + 1) * nf], ref), f"rank {rank}"
+
+
+def test_pinhole_projection_falls_back_for_huge_and_non_finite_votes(hp_mod, oracle):
+    """k_vote projects with the pinhole form of the intrinsic matrix (five of nine products are x * 0 / z * 1) only for
+    waves whose operands are finite and small; leaves with huge or infinite offset votes (0 * inf = NaN has to propagate
+    through space_to_img_coord, types.rs:424-428) must take the general expression.  Same grids, votes and poses."""
+    rs = np.random.RandomState(11)
+    forest = synth.fit_forest(6, 8, synth.FOREST_SEED_BASE + 41, n_frames=10, subset=1200)
+    voting = np.flatnonzero(forest.leaf_prob > 0)
+    for L in voting[rs.rand(voting.size) < 0.3]:
+        ob, oe = int(forest.off_begin[L]), int(forest.off_begin[L + 1])
+        kind = rs.randint(0, 4)
+        k = ob + rs.randint(0, oe - ob)
+        if kind == 0:
+            forest.offsets[k] = [3.0e35, -2.0e33, 1.0e31]          # finite, beyond the fast path's bound
+        elif kind == 1:
+            forest.offsets[k, 2] = -np.inf                         # nz = +inf
+        elif kind == 2:
+            forest.offsets[k, 0] = np.inf                          # nx = -inf: 0 * inf = NaN in the general product
+        else:
+            forest.offsets[k] = [np.nan, 0.0, -50.0]
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 320, 240
+    frames = synth.biwi_batch(3, w, h, first=70)
+    _product_mode_check(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h))
+    # and with the taps on (rotation records instead of the leaf histogram)
+    from test_gpu_parity import _check_frames
+    _check_frames(hp_mod, oracle, forest, model, frames[:2], synth.default_intrinsic(w, h), full=True)
