@@ -1058,7 +1058,9 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
 // (leaf probabilities, the frame's hit counter, the leaf templates) that used to end every
 // k_traverse workgroup are hidden here by plain occupancy.
 #define EMIT_THREADS 256
-#define EMIT_BATCH 16
+// EB = trees handled per batch of gathers: the smallest instance that holds all T trees keeps the registers (and with them the
+// occupancy of this latency-bound kernel) in proportion to the forest: 62 VGPRs at EB = 8, 80 at 10, 122 at 16.
+template <int EB>
 __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
     const int frame = blockIdx.y, lane = threadIdx.x & (WAVE - 1);
     const int pp = a.px * a.py;
@@ -1094,37 +1096,37 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
     bool gated = false;
     const int32_t *wl = a.win_leaf + (size_t)frame * a.win_cap * T + w;
     unsigned long long voting = 0;          // bit t: the leaf reached in tree t casts votes (T <= 64; else recomputed below)
-    uint32_t rotv = 0, l[EMIT_BATCH];       // bit k: leaf l[k] casts rotation votes and the window passed the gate
+    uint32_t rotv = 0, l[EB];       // bit k: leaf l[k] casts rotation votes and the window passed the gate
 #pragma unroll
-    for (int k = 0; k < EMIT_BATCH; ++k) l[k] = 0;
+    for (int k = 0; k < EB; ++k) l[k] = 0;
     uint16_t zc = 0;                        // depth at the window centre
     if (live) {
         gp = a.win_patch[(size_t)frame * a.win_cap + w];
-        // Batches of EMIT_BATCH trees: the leaf ids, then their probabilities and flags, are requested
+        // Batches of EB trees: the leaf ids, then their probabilities and flags, are requested
         // together, so a window costs two dependent round trips per batch (one batch for T <= 16).
         double prob = 0.0;
-        for (int t0 = 0; t0 < T; t0 += EMIT_BATCH) {
-            uint32_t lf[EMIT_BATCH];
-            double pr[EMIT_BATCH];
-            uint4 g[EMIT_BATCH];
+        for (int t0 = 0; t0 < T; t0 += EB) {
+            uint32_t lf[EB];
+            double pr[EB];
+            uint4 g[EB];
 #pragma unroll
-            for (int k = 0; k < EMIT_BATCH; ++k) l[k] = (uint32_t)wl[(size_t)min(t0 + k, T - 1) * a.win_cap];
+            for (int k = 0; k < EB; ++k) l[k] = (uint32_t)wl[(size_t)min(t0 + k, T - 1) * a.win_cap];
             if (t0 == 0) {
                 // window centre (for prediction.rs:551-554), requested now: its latency hides behind the batch
                 const int gyi = (int)(gp / (uint32_t)a.nx), gxi = (int)gp - gyi * a.nx;
                 zc = a.frames[(size_t)frame * a.w * a.h + (size_t)(gyi * a.step + a.lh) * a.w + gxi * a.step + a.lw];
             }
 #pragma unroll
-            for (int k = 0; k < EMIT_BATCH; ++k) g[k] = ((const uint4 *)(a.f.tpl + l[k]))[3];             // n_rot, flags, prob
+            for (int k = 0; k < EB; ++k) g[k] = ((const uint4 *)(a.f.tpl + l[k]))[3];             // n_rot, flags, prob
 #pragma unroll
-            for (int k = 0; k < EMIT_BATCH; ++k) { lf[k] = g[k].y; pr[k] = __hiloint2double((int)g[k].w, (int)g[k].z); }
+            for (int k = 0; k < EB; ++k) { lf[k] = g[k].y; pr[k] = __hiloint2double((int)g[k].w, (int)g[k].z); }
 #pragma unroll
-            for (int k = 0; k < EMIT_BATCH; ++k)
+            for (int k = 0; k < EB; ++k)
                 if (t0 + k < T) {
                     prob = __dadd_rn(prob, pr[k]);                                   // tree order, f64 (prediction.rs:582-584)
                     if ((lf[k] & LF_PROB) && (lf[k] & (LF_ROT | LF_OFF))) {
                         cnt++; voting |= 1ull << ((t0 + k) & 63);
-                        if (lf[k] & LF_ROT) rotv |= 1u << k;                          // (only read when T <= EMIT_BATCH)
+                        if (lf[k] & LF_ROT) rotv |= 1u << k;                          // (only read when T <= EB)
                     }
                 }
         }
@@ -1136,11 +1138,11 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
     // Leaf histogram (rotation votes per leaf, read by k_vote and k_cluster): neighbouring windows -- adjacent
     // lanes -- mostly reach the same leaf of a tree, so runs of equal leaves along the wave are counted with
     // one ballot and added by the run's first lane: a few times fewer global atomics than one per hit record.
-    const bool hist_here = a.leaf_hits && T <= EMIT_BATCH;
+    const bool hist_here = a.leaf_hits && T <= EB;
     if (hist_here) {
         uint32_t *lhist = a.leaf_hits + (size_t)frame * a.f.n_leaves;
 #pragma unroll
-        for (int k = 0; k < EMIT_BATCH; ++k) {
+        for (int k = 0; k < EB; ++k) {
             if (k >= T) continue;                                                    // (uniform)
             const bool v = (rotv >> k) & 1u;
             const uint32_t key = v ? l[k] : 0xFFFFFFFFu;
@@ -1238,7 +1240,13 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
 hipError_t dh_launch_emit(const EmitArgs &a, hipStream_t s) {
     if (a.n_frames == 0 || a.tiles == 0 || a.npatch == 0) return hipSuccess;
     if (a.n_frames > 65535) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(k_emit, dim3((a.npatch + EMIT_THREADS - 1) / EMIT_THREADS, a.n_frames), dim3(EMIT_THREADS), 0, s, a);
+    const dim3 grid((a.npatch + EMIT_THREADS - 1) / EMIT_THREADS, a.n_frames), block(EMIT_THREADS);
+    const uint32_t T = a.f.n_trees;
+    if (T <= 4) hipLaunchKernelGGL(k_emit<4>, grid, block, 0, s, a);
+    else if (T <= 8) hipLaunchKernelGGL(k_emit<8>, grid, block, 0, s, a);
+    else if (T <= 10) hipLaunchKernelGGL(k_emit<10>, grid, block, 0, s, a);
+    else if (T <= 12) hipLaunchKernelGGL(k_emit<12>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_emit<16>, grid, block, 0, s, a);
     return hipGetLastError();
 }
 
