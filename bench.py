@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (other configs, PCIe-inclusive rates): profiling runs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
+    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight per GPU (predictors / streams that consecutive steps alternate between)")
     ap.add_argument("--dump-poses", default=None, help="rank 0 writes the gathered pose records of the last timed step (all ranks, rank order) as .npy")
     return ap.parse_args()
 
@@ -107,11 +108,17 @@ def main():
     frames = torch.from_numpy(frames_np.view(np.int16)).to(dev)          # resident in HBM before timing
     hp = HoughPrediction(forest, model, device=local_rank)
     hp.reserve(NF, W, H)
+    # pipeline depth: consecutive steps alternate between this many predictors (own workspace, own stream), so that the
+    # latency-bound tail kernels of one batch run beside the head kernels of the next; every step is still one whole batch
+    depth = 1 if args.graph else max(1, args.pipeline)
+    hps = [hp] + [HoughPrediction(forest, model, device=local_rank) for _ in range(depth - 1)]
+    for q in hps[1:]:
+        q.reserve(NF, W, H)
     stream = torch.cuda.current_stream(dev)
     # the shard -> predict -> gather loop is the package's (depthhead_amd.dist.ShardedPredictor): two pose buffers, the
     # RCCL all-gather of step i overlaps the kernels of step i + 1
     from depthhead_amd.dist import ShardedPredictor
-    sp = ShardedPredictor(hp, NF, W, H, intr, device=dev)
+    sp = ShardedPredictor(hps, NF, W, H, intr, device=dev)
     poses = sp.pose_bufs[0]
     if args.graph:
         sp.capture(frames.data_ptr())
@@ -203,7 +210,8 @@ def main():
 
     also = None
     if world == 1 and not args.no_extras and not custom_workload():
-        hp.close()
+        for q in hps:
+            q.close()
         hp = None
         also = other_configs(args, dev, stream)
 
@@ -258,7 +266,8 @@ def main():
                                    f"({forest.n_nodes} nodes, {forest.n_leaves} leaves), stride-{args.stride} "
                                    f"80x80 patches, 20 mean-shift iterations",
                        "frames_per_gpu": NF, "width": W, "height": H, "trees": args.trees, "max_depth": args.depth,
-                       "stride": args.stride, "parallelism": f"frame-sharded x{world}, RCCL all-gather of poses"},
+                       "stride": args.stride, "parallelism": f"frame-sharded x{world}, RCCL all-gather of poses",
+                       "batches_in_flight": depth},
             "roofline": roof,
             "repeat_ms_per_step": [round(r, 4) for r in repeats],
             "kernels_ms": kernels,
@@ -286,7 +295,8 @@ def main():
         print(json.dumps(out), flush=True)
 
     if hp is not None:
-        hp.close()
+        for q in hps:
+            q.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

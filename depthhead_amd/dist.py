@@ -85,55 +85,73 @@ def predict_stream(hp, frames, intrinsic, group=None) -> np.ndarray:
 
 class ShardedPredictor:
     """The steady-state form of `predict_stream` for device-resident shards (what `bench.py --gpus N` times):
-    this rank's `n_local` frames already sit in HBM; `submit()` enqueues the local batch on `stream` and starts
-    the all-gather of its pose records (on RCCL's own stream, asynchronous); two pose / gather buffers alternate
-    so that the gather of step i overlaps the kernels of step i + 1.  `wait()` returns the gathered records of
-    the oldest outstanding step.  With `backend == "gloo"` (rehearsal on one device, or CPU-only hosts) the
-    records are staged through host memory.  World size 1: no collective at all."""
+    this rank's `n_local` frames already sit in HBM; `submit()` enqueues the local batch and starts the all-gather of
+    its pose records (on RCCL's own stream, asynchronous); `wait()`-free: buffers alternate so that the gather of
+    step i overlaps the kernels of step i + 1, and `fence()` drains everything.
+
+    `hp` may be ONE predictor or a list of them (pipeline depth = len): consecutive steps then alternate between the
+    predictors, each on a stream of its own, so that the latency-bound tail kernels of batch i (vote, mean shift) run
+    beside the bandwidth / issue-bound head kernels of batch i + 1 (`dh_predictor` objects are independent: "distinct
+    predictors may run concurrently", include/depthhead_hip.h).  Measured on one MI355X: 505 k -> 549 k frames/s at depth 2,
+    561 k at depth 3 (`tools/two_stream.py`).  Every step still processes one whole batch through every kernel.
+
+    With `backend == "gloo"` (rehearsal on one device, or CPU-only hosts) the records are staged through host memory.
+    World size 1: no collective at all."""
 
     def __init__(self, hp, n_local: int, w: int, h: int, intrinsic, group=None, device=None):
         import torch
         import torch.distributed as dist
-        self.hp, self.n_local, self.w, self.h, self.intrinsic, self.group = hp, n_local, w, h, intrinsic, group
+        self.hps = list(hp) if isinstance(hp, (list, tuple)) else [hp]
+        self.hp = self.hps[0]
+        self.depth = len(self.hps)
+        self.n_local, self.w, self.h, self.intrinsic, self.group = n_local, w, h, intrinsic, group
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.rank = self.dist.get_rank(group) if self.dist else 0
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.on_device = self.dist is None or self.dist.get_backend(group) == "nccl"
         nb = n_local * POSE_BYTES
-        self.pose_bufs = [torch.zeros(nb, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        # one pose / gather buffer pair per slot; with a single predictor two slots still alternate (gather i beside kernels i + 1)
+        self.slots = max(2, self.depth) if self.world > 1 else self.depth
+        self.pose_bufs = [torch.zeros(nb, dtype=torch.uint8, device=self.device) for _ in range(self.slots)]
         gdev = self.device if self.on_device else torch.device("cpu")
-        self.gathered = [torch.zeros(self.world * nb, dtype=torch.uint8, device=gdev) for _ in range(2)] if self.world > 1 else None
-        self.pending = [None, None]
+        self.gathered = [torch.zeros(self.world * nb, dtype=torch.uint8, device=gdev) for _ in range(self.slots)] if self.world > 1 else None
+        self.pending = [None] * self.slots
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.depth)] if self.depth > 1 else None
         self.count = 0
         self.graph = False
 
     def capture(self, frames_ptr: int):
-        """Replay the local batch from a hipGraph (launch-bound configs).  One pose buffer then: a replay
-        writes where the capture wrote, so each step waits for its own gather before the next replay."""
+        """Replay the local batch from a hipGraph (launch-bound configs).  One predictor and one pose buffer then: a
+        replay writes where the capture wrote, so each step waits for its own gather before the next replay."""
         self.hp.graph_capture(frames_ptr, self.n_local, self.w, self.h, self.intrinsic, self.pose_bufs[0].data_ptr())
         self.graph = True
+        self.depth, self.hps, self.streams = 1, self.hps[:1], None
 
     def submit(self, frames_ptr: int, stream) -> int:
-        """Enqueue one step; returns the buffer index it uses."""
-        b = self.count & 1 if (self.world > 1 and not self.graph) else 0
+        """Enqueue one step (`stream` is used at depth 1; deeper pipelines bring their own streams); returns the slot."""
+        import torch
+        b = 0 if self.graph else self.count % self.slots
+        k = self.count % self.depth
         self.count += 1
         if self.pending[b] is not None:
             self.pending[b].wait()                      # stream-side wait for RCCL; the buffer is free again
             self.pending[b] = None
+        st = self.streams[k] if self.streams else stream
         if self.graph:
-            self.hp.graph_launch(stream.cuda_stream)
+            self.hp.graph_launch(st.cuda_stream)
         else:
-            self.hp.predict_batch_device(frames_ptr, self.n_local, self.w, self.h, self.intrinsic, self.pose_bufs[b].data_ptr(),
-                                         stream=stream.cuda_stream)
+            self.hps[k].predict_batch_device(frames_ptr, self.n_local, self.w, self.h, self.intrinsic, self.pose_bufs[b].data_ptr(),
+                                             stream=st.cuda_stream)
         if self.world > 1:
-            src = self.pose_bufs[b] if self.on_device else self.pose_bufs[b].cpu()
-            self.pending[b] = self.dist.all_gather_into_tensor(self.gathered[b], src, group=self.group, async_op=True)
+            with torch.cuda.stream(st):                 # the collective (or the staging copy) orders itself after this step's kernels
+                src = self.pose_bufs[b] if self.on_device else self.pose_bufs[b].cpu()
+                self.pending[b] = self.dist.all_gather_into_tensor(self.gathered[b], src, group=self.group, async_op=True)
         return b
 
     def fence(self):
         import torch
-        for i in range(2):
+        for i in range(self.slots):
             if self.pending[i] is not None:
                 self.pending[i].wait()
                 self.pending[i] = None
@@ -143,5 +161,5 @@ class ShardedPredictor:
 
     def last_poses(self) -> np.ndarray:
         """Gathered pose records (all ranks' shards in rank order) of the most recent step; call after fence()."""
-        b = (self.count - 1) & 1 if (self.world > 1 and not self.graph) else 0
+        b = 0 if self.graph else (self.count - 1) % self.slots
         return poses_from_bytes(self.gathered[b] if self.world > 1 else self.pose_bufs[b])
