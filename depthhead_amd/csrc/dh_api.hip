@@ -241,7 +241,7 @@ struct Knobs {
     int tile_x = 0, tile_y = 0;       // DH_TILE=px,py
     int box_band = 64;                // DH_BOX_BAND
     int max_resident = 512;           // DH_MAX_RESIDENT_FRAMES
-    int chunks = 1;                   // DH_CHUNKS
+    int chunks = 0;                   // DH_CHUNKS: forked sub-batches per call; 0 = automatic (two once a call brings >= 512 frames)
     int stage_chunk = 64;             // DH_STAGE_CHUNK: frames per upload chunk of the host entry points (copy of chunk k + 1 overlaps the kernels of chunk k)
     int host_threads = 8;             // DH_HOST_THREADS: host threads that validate / pack run-length coded payloads
 #ifdef DH_PROFILING_KNOBS
@@ -261,7 +261,7 @@ static Knobs read_knobs() {
     if (const char *e = getenv("DH_TILE")) sscanf(e, "%d,%d", &k.tile_x, &k.tile_y);
     k.box_band = std::max(1, geti("DH_BOX_BAND", 64));
     k.max_resident = std::max(1, geti("DH_MAX_RESIDENT_FRAMES", 512));
-    k.chunks = std::max(1, std::min(8, geti("DH_CHUNKS", 1)));
+    k.chunks = std::max(0, std::min(8, geti("DH_CHUNKS", 0)));
     k.stage_chunk = std::max(1, geti("DH_STAGE_CHUNK", 64));
     k.host_threads = std::max(1, std::min(64, geti("DH_HOST_THREADS", (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())))));
 #ifdef DH_PROFILING_KNOBS
@@ -331,6 +331,7 @@ struct dh_predictor {
     // captured batch (hipGraph)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    bool capturing = false;          // inside dh_graph_capture: one ordered pass on the capture stream
     bool graph_stale = false;        // the workspace a captured batch points into was reallocated: dh_graph_launch refuses
     // taps
     bool debug = false;
@@ -518,7 +519,7 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     if (rc == DH_OK) rc = build_kernel_table(p);
     for (auto &e : p->ev)
         if (rc == DH_OK) hipstep(hipEventCreate(&e), "hipEventCreate");
-    p->chunks = p->knobs.chunks;   // measured on MI355X: forked sub-batches do not overlap usefully (1.016 vs 1.022 ms), kept as a knob
+    p->chunks = p->knobs.chunks;
     if (rc == DH_OK) hipstep(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming), "hipEventCreate");
     if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
     for (auto &e : p->ev_stage)
@@ -848,10 +849,12 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
         const float *mg = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
         const double *rg = rot_guess ? rot_guess + (size_t)f0 * 3 : nullptr;
         const uint8_t *gm = guess_mask ? guess_mask + f0 : nullptr;
-        // Optional forked sub-batches (DH_CHUNKS > 1): measured on MI355X to give no overlap gain
-        // (1.016 vs 1.022 ms per 256 frames), so one ordered pass is the default.
-        int chunks = p->chunks;
-        if (p->profiling || p->debug || m < 2 * DH_MIN_CHUNK_FRAMES) chunks = 1;
+        // Forked sub-batches: two halves of the slice on two streams let the latency-bound tail kernels of one half run
+        // beside the head kernels of the other.  Measured on MI355X: it pays once each half still has >= 256 frames
+        // (512 frames per call: 479 k -> 533 k frames/s with 2 chunks, 483 k with 4; 256 frames per call: no gain),
+        // so that is the automatic choice; DH_CHUNKS forces a count.
+        int chunks = p->chunks > 0 ? p->chunks : (m >= 512 ? 2 : 1);
+        if (p->profiling || p->debug || p->capturing || m < 2 * DH_MIN_CHUNK_FRAMES) chunks = 1;
         chunks = std::min(chunks, m / DH_MIN_CHUNK_FRAMES);
         if (chunks <= 1) {
             rc = enqueue_range(p, fr, 0, m, w, h, K, kinv, mg, rg, gm, out + f0, s, p->profiling);
@@ -1183,7 +1186,9 @@ extern "C" int dh_graph_capture(dh_predictor *p, const uint16_t *frames, int n, 
     dh_graph_destroy(p);
     HIP_TRY(hipStreamSynchronize(p->own_stream));
     HIP_TRY(hipStreamBeginCapture(p->own_stream, hipStreamCaptureModeThreadLocal));
+    p->capturing = true;
     rc = dh_predict_batch_device(p, frames, n, w, h, K, midp_guess, rot_guess, guess_mask, out, p->own_stream);
+    p->capturing = false;
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(p->own_stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
