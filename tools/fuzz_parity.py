@@ -4,7 +4,7 @@ with many more seeded configurations, biased towards multi-tile frames and unifo
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from depthhead_amd import synth
+from depthhead_amd import biwi, synth
 from depthhead_amd.prediction import HoughPrediction, IntrinsicMatrix
 from oracle import pyoracle
 
@@ -70,6 +70,13 @@ for case in range(first, first + count):
             if api:                                   # (after the taps: these runs invalidate them)
                 masks = hp.predict_mask(frames.astype(np.uint16))
                 hough = hp.build_hough_votes(frames.astype(np.uint16), IntrinsicMatrix(K))
+                blurred = hp.build_hough_image(frames.astype(np.uint16), IntrinsicMatrix(K)) if model.gaussian_sigma > 0 else None
+                p2d = hp.predict_parameter_from2dhough(frames.astype(np.uint16), IntrinsicMatrix(K)) if model.gaussian_sigma > 0 else None
+                hp.debug_enable(False)
+                rle = hp.predict_batch_rle([biwi.encode_depth(f) for f in frames.astype(np.uint16)], IntrinsicMatrix(K), midp, rot)
+                if rle.tobytes() != poses.tobytes():
+                    bad += 1
+                    print(f"MISMATCH case {case}: dh_predict_batch_rle differs from dh_predict_batch")
     except Exception as e:   # geometry refused (e.g. patch too large): fine as long as it is a clean error
         refused += 1
         print("case", case, "refused:", str(e)[:80])
@@ -88,6 +95,11 @@ for case in range(first, first + count):
             ok = np.array_equal(masks[i], pyoracle.predict_mask(forest, model, frames[i])) and np.array_equal(hough[i], pyoracle.hough_image(forest, model, frames[i], K))
             if not ok:
                 print("   (mask / hough image differ)")
+            if ok and blurred is not None:
+                m2, _ = pyoracle.predict_from2dhough(forest, model, frames[i], K)
+                ok = np.array_equal(blurred[i], pyoracle.build_hough_image(forest, model, frames[i], K)) and np.array_equal(p2d["mid_point"][i], m2, equal_nan=True)
+                if not ok:
+                    print("   (blurred hough image / 2-D prediction differ)")
         if not ok:
             bad += 1
             what = [nm for nm, eq in (("leaf", np.array_equal(leaf[i], ref.leaf_idx)), ("pos_grid", np.array_equal(pg[i], ref.pos_grid)),
