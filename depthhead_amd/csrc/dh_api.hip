@@ -242,6 +242,7 @@ struct Knobs {
     int box_band = 64;                // DH_BOX_BAND
     int max_resident = 512;           // DH_MAX_RESIDENT_FRAMES
     int chunks = 0;                   // DH_CHUNKS: forked sub-batches per call; 0 = automatic (two once a call brings >= 512 frames)
+    bool no_general_int = false;      // DH_NO_GENERAL_INT: general path with the f64 divisions on every visit
     int stage_chunk = 64;             // DH_STAGE_CHUNK: frames per upload chunk of the host entry points (copy of chunk k + 1 overlaps the kernels of chunk k)
     int host_threads = 8;             // DH_HOST_THREADS: host threads that validate / pack run-length coded payloads
 #ifdef DH_PROFILING_KNOBS
@@ -262,6 +263,7 @@ static Knobs read_knobs() {
     k.box_band = std::max(1, geti("DH_BOX_BAND", 64));
     k.max_resident = std::max(1, geti("DH_MAX_RESIDENT_FRAMES", 512));
     k.chunks = std::max(0, std::min(8, geti("DH_CHUNKS", 0)));
+    k.no_general_int = getenv("DH_NO_GENERAL_INT") != nullptr;
     k.stage_chunk = std::max(1, geti("DH_STAGE_CHUNK", 64));
     k.host_threads = std::max(1, std::min(64, geti("DH_HOST_THREADS", (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())))));
 #ifdef DH_PROFILING_KNOBS
@@ -283,6 +285,7 @@ struct dh_predictor {
     uint16_t *zeros = nullptr;   // device, 64 zero bytes (k_boxsum reads them for columns right of the image)
     bool f_uniform = false;      // forest has one split-rectangle size
     int f_rw = 0, f_rh = 0;
+    void *nodes_g = nullptr;     // NodeG[n_nodes]: general-path nodes with integer split bounds (patches up to 255 x 255), else NULL
     void *nodes_u = nullptr;     // 16-byte compact nodes for the current region layout (uniform path)
     long long nodes_u_key = 0;   // (ss_row, swizzle) the compact nodes were built for
     hipStream_t own_stream = nullptr;
@@ -507,6 +510,37 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     STEP(dev_alloc(p, &p->kern_ord, DH_GRID3));
     STEP(dev_alloc(p, &p->zeros, 32));
     { uint4 *nu = nullptr; STEP(dev_alloc(p, &nu, p->n_nodes, true)); p->nodes_u = nu; }
+    if (rc == DH_OK && prm->subimage_width <= 255 && prm->subimage_height <= 255 && p->n_nodes > 0) {
+        // Integer split bounds of the general path (NodeG, see k_traverse): with C_i = max(c_i, 1), delta = (s1 C2 - s2 C1) / (C1 C2)
+        // and |d - delta| < 2^-35, so D = s1 C2 - s2 C1 <= floor((thr - 2^-34) C1 C2 - pad) decides Zero and
+        // D >= ceil((thr + 2^-34) C1 C2 + pad) decides One; pad covers the rounding of these f64 products (C1 C2 < 2^32,
+        // |thr| <= 65535: the products are below 2^48, their rounding error below 2^-4) with room to spare.
+        std::vector<NodeG> ng(p->n_nodes);
+        for (uint32_t i = 0; i < p->n_nodes; ++i) {
+            const dh_node &nd = f->nodes[i];
+            NodeG o{};
+            for (int k = 0; k < 4; ++k) { o.r1[k] = (uint8_t)nd.r1[k]; o.r2[k] = (uint8_t)nd.r2[k]; }
+            const uint32_t c1 = (uint32_t)(nd.r1[2] - nd.r1[0]) * (uint32_t)(nd.r1[3] - nd.r1[1]);
+            const uint32_t c2 = (uint32_t)(nd.r2[2] - nd.r2[0]) * (uint32_t)(nd.r2[3] - nd.r2[1]);
+            const uint32_t C1 = std::max(c1, 1u), C2 = std::max(c2, 1u);            // <= 255 * 255
+            o.cc = C1 | (C2 << 16);
+            o.child_zero = nd.child_zero; o.child_one = nd.child_one;
+            const double thr = nd.threshold, cc = (double)C1 * (double)C2;
+            if (thr >= 65535.0) { o.ilo = INT64_MAX - 16; o.amb = 0; }              // mean difference <= 65535: never greater
+            else if (thr < -65535.0) { o.ilo = INT64_MIN; o.amb = 0; }             // >= -65535: always greater
+            else {
+                const double m = 5.820766091346741e-11;                             // 2^-34
+                const double lo = floor((thr - m) * cc - 1.0), hi = ceil((thr + m) * cc + 1.0);
+                o.ilo = (int64_t)lo;
+                o.amb = (uint32_t)std::min<int64_t>((int64_t)hi - (int64_t)lo - 1, 0xffffffffll);
+            }
+            ng[i] = o;
+        }
+        NodeG *dg = nullptr;
+        STEP(dev_alloc(p, &dg, p->n_nodes, true));
+        if (rc == DH_OK && hipMemcpy(dg, ng.data(), ng.size() * sizeof(NodeG), hipMemcpyHostToDevice) != hipSuccess) rc = fail(DH_EHIP, "hipMemcpy(NodeG)");
+        p->nodes_g = dg;
+    }
 #undef STEP
     auto hipstep = [&](hipError_t e, const char *what) {
         if (rc == DH_OK && e != hipSuccess) rc = fail(DH_EHIP, "%s: %s", what, hipGetErrorString(e));
@@ -740,7 +774,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.nx = g.nx; ta.ny = g.ny; ta.px = g.px; ta.py = g.py; ta.tiles_x = g.tiles_x; ta.tiles_y = g.tiles_y;
         ta.ss_max = g.ss_max; ta.ss_row = g.ss_row; ta.swz_log2 = g.swz_log2; ta.swz_q = g.swz_q;
         ta.uniform = g.uniform ? 1 : 0; ta.rw = p->f_rw; ta.rh = p->f_rh; ta.area = (uint32_t)(p->f_rw * p->f_rh);
-        ta.nodes_u = p->nodes_u;
+        ta.nodes_u = p->nodes_u; ta.nodes_g = p->knobs.no_general_int ? nullptr : p->nodes_g;
         ta.box = box; ta.box_plane = g.box_plane; ta.box_rows = g.box_rows;
         ta.tile_flags = tile_flags;
 #ifdef DH_PROFILING_KNOBS

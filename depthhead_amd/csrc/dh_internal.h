@@ -82,6 +82,15 @@ struct __attribute__((aligned(16))) HitRot {
     uint32_t n_rot;    // distinct fine bins | distinct guess-grid cells << 16
 };
 
+// General-path node with integer split bounds (k_traverse<false, true>, built on the host by dh_predictor_create).
+struct __attribute__((aligned(16))) NodeG {
+    uint8_t  r1[4], r2[4];      // x0, y0, x1, y1 of the two rectangles
+    int64_t  ilo;
+    int32_t  child_zero, child_one;
+    uint32_t amb;               // integers strictly between ilo and ihi (saturating)
+    uint32_t cc;                // C1 | C2 << 16
+};
+
 struct TraverseArgs {
     const uint16_t *frames;
     int n_frames, w, h;
@@ -99,6 +108,7 @@ struct TraverseArgs {
     int box_plane, box_rows;
     const uint8_t *tile_flags; // [n_frames][tiles] 1 = the tile's region holds a non-zero box sum (k_boxsum) / its footprint a non-zero pixel (k_pixflags)
     const void *nodes_u;    // NodeU[n_nodes], built by k_nodes_compact for this region layout
+    const void *nodes_g;    // general path: NodeG[n_nodes] with integer split bounds (patches up to 255 x 255), else NULL
     unsigned long long *dbg_stamps; // profiling: [8] summed cycles per phase (region build, gate, walks) over all workgroups (env DH_TRAV_STAMPS)
     int stop_phase;         // profiling knob (env DH_TRAV_STOP): 0 = run everything, 9 / 1 / 3 = return at entry / after the region build / after the gate
     DevForest f;

@@ -830,6 +830,84 @@ __device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32
     }
 }
 
+// GI (general path, patches of at most 255 x 255): split tests decided on integers.  With C_i = max(c_i, 1) (an empty
+// rectangle sums to 0, types.rs:335-338) the real difference of the two means is delta = (s1 C2 - s2 C1) / (C1 C2), and the
+// reference's d = fl(fl(s1 / c1) - fl(s2 / c2)) satisfies |d - delta| < 2^-35 as on the uniform path, so
+// D = s1 C2 - s2 C1 (64-bit) is compared with per-node bounds ilo = floor((thr - 2^-34) C1 C2 - pad) and
+// ihi = ilo + 1 + amb (NodeG, built on the host): D <= ilo -> Zero, D >= ihi -> One, anything between takes the reference's
+// own two f64 divisions.  Replaces ~60 VALU instructions of f64 division per visit by two 32 x 32 -> 64 multiplies.
+
+// Root-to-leaf walks of the general path with the integer split test of NodeG (see k_traverse), W walks per lane in lock
+// step like walk_uniform.  sat is the tile's summed-area table modulo 2^32 with row stride ss.
+template <int W>
+__device__ __forceinline__ void walk_general_int(const TraverseArgs &a, const uint32_t *sat, int32_t *wleaf, int32_t *dleaf, const uint32_t *active,
+                                                 const uint32_t *agp, int n_active, int total, int cx, int ss, int T) {
+    const int tid = threadIdx.x;
+    const NodeG *nodes_g = (const NodeG *)a.nodes_g;
+    const float r_active = 1.0f / (float)n_active, r_cx = 1.0f / (float)cx;
+    for (int k0 = tid; k0 < total; k0 += W * TRAV_THREADS) {
+        int cur[W], dst[W], ddst[W];
+        const uint32_t *sp[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const int k = k0 + i * TRAV_THREADS;
+            const bool has = k < total;
+            const int kk = has ? k : k0;
+            const int t = div_small(kk, n_active, r_active), slot = kk - t * n_active;
+            const int p = (int)active[slot];
+            const int py = div_small(p, cx, r_cx), px = p - py * cx;
+            sp[i] = sat + py * a.step * ss + px * a.step;
+            dst[i] = t * a.win_cap + slot;
+            ddst[i] = dleaf ? (int)agp[slot] * T + t : 0;
+            cur[i] = has ? a.f.roots[t] : -1;
+        }
+        for (;;) {
+            bool go = false;
+#pragma unroll
+            for (int i = 0; i < W; ++i) go |= cur[i] >= 0;
+            if (!go) break;
+            uint4 n0[W], n1[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const uint4 *np = (const uint4 *)(nodes_g + (cur[i] >= 0 ? cur[i] : 0));       // a finished walk re-reads node 0 harmlessly
+                n0[i] = np[0]; n1[i] = np[1];
+            }
+            uint32_t c[W][8];
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const int ax0 = n0[i].x & 0xff, ay0 = (n0[i].x >> 8) & 0xff, ax1 = (n0[i].x >> 16) & 0xff, ay1 = n0[i].x >> 24;
+                const int bx0 = n0[i].y & 0xff, by0 = (n0[i].y >> 8) & 0xff, bx1 = (n0[i].y >> 16) & 0xff, by1 = n0[i].y >> 24;
+                const uint32_t *q = sp[i];
+                c[i][0] = q[ay1 * ss + ax1]; c[i][1] = q[ay0 * ss + ax1]; c[i][2] = q[ay1 * ss + ax0]; c[i][3] = q[ay0 * ss + ax0];
+                c[i][4] = q[by1 * ss + bx1]; c[i][5] = q[by0 * ss + bx1]; c[i][6] = q[by1 * ss + bx0]; c[i][7] = q[by0 * ss + bx0];
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const uint32_t s1 = c[i][0] - c[i][1] - c[i][2] + c[i][3], s2 = c[i][4] - c[i][5] - c[i][6] + c[i][7];
+                const uint32_t C1 = n1[i].w & 0xffffu, C2 = n1[i].w >> 16;
+                const long long D = (long long)((unsigned long long)s1 * C2) - (long long)((unsigned long long)s2 * C1);
+                const long long ilo = (long long)(((unsigned long long)n0[i].w << 32) | n0[i].z);
+                bool one = D > ilo;
+                if (cur[i] >= 0 && one && (unsigned long long)(D - ilo - 1) < (unsigned long long)n1[i].z) {
+                    // inside the band the integers cannot decide: the reference's own arithmetic (types.rs:335-338, houghforest.rs:188-191)
+                    const dh_node nd = a.f.nodes[cur[i]];
+                    const uint32_t c1 = (uint32_t)((nd.r1[2] - nd.r1[0]) * (nd.r1[3] - nd.r1[1])), c2 = (uint32_t)((nd.r2[2] - nd.r2[0]) * (nd.r2[3] - nd.r2[1]));
+                    const double a1 = c1 ? __ddiv_rn((double)s1, (double)c1) : 0.0;
+                    const double a2 = c2 ? __ddiv_rn((double)s2, (double)c2) : 0.0;
+                    one = __dsub_rn(a1, a2) > nd.threshold;
+                }
+                if (cur[i] >= 0) cur[i] = one ? (int)n1[i].y : (int)n1[i].x;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            if (k0 + i * TRAV_THREADS < total) {
+                wleaf[dst[i]] = ~cur[i];
+                if (dleaf) dleaf[ddst[i]] = ~cur[i];
+            }
+    }
+}
+
 #ifdef DH_PROFILING_KNOBS
 #define STAMP(k)                                                                        \
     if (a.dbg_stamps && tid == 0) {                                                     \
@@ -841,7 +919,7 @@ __device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32
 #define STAMP(k)
 #endif
 
-template <bool UNI>
+template <bool UNI, bool GI>
 __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
@@ -1022,6 +1100,10 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         else if (per_lane == 2) walk_uniform<2>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
         else if (per_lane == 3) walk_uniform<3>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
         else walk_uniform<4>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+    } else if (GI) {
+        const int per_lane = (total + TRAV_THREADS - 1) / TRAV_THREADS;
+        if (per_lane <= 1) walk_general_int<1>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+        else walk_general_int<2>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
     } else {
         for (int k = tid; k < total; k += TRAV_THREADS) {
             const int t = div_small(k, n_active, 1.0f / (float)n_active), slot = k - t * n_active;
@@ -1255,8 +1337,9 @@ hipError_t dh_launch_emit(const EmitArgs &a, hipStream_t s) {
 hipError_t dh_kernels_init() {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)k_traverse<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -1268,8 +1351,9 @@ hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream
     if (tiles == 0 || fb == 0) return hipSuccess;
     if (tiles > 65535 || fb > 65535) return hipErrorInvalidConfiguration;
     const dim3 grid(8, tiles, fb);
-    if (a.uniform) hipLaunchKernelGGL(k_traverse<true>, grid, dim3(TRAV_THREADS), lds_bytes, s, a);
-    else hipLaunchKernelGGL(k_traverse<false>, grid, dim3(TRAV_THREADS), lds_bytes, s, a);
+    if (a.uniform) hipLaunchKernelGGL((k_traverse<true, false>), grid, dim3(TRAV_THREADS), lds_bytes, s, a);
+    else if (a.nodes_g) hipLaunchKernelGGL((k_traverse<false, true>), grid, dim3(TRAV_THREADS), lds_bytes, s, a);
+    else hipLaunchKernelGGL((k_traverse<false, false>), grid, dim3(TRAV_THREADS), lds_bytes, s, a);
     return hipGetLastError();
 }
 

@@ -388,3 +388,50 @@ def test_pinhole_projection_falls_back_for_huge_and_non_finite_votes(hp_mod, ora
     # and with the taps on (rotation records instead of the leaf histogram)
     from test_gpu_parity import _check_frames
     _check_frames(hp_mod, oracle, forest, model, frames[:2], synth.default_intrinsic(w, h), full=True)
+
+
+@pytest.mark.parametrize("int_test", [True, False])
+def test_mixed_rectangles_with_thresholds_on_reachable_differences(hp_mod, oracle, int_test):
+    """General path (rectangles of different sizes, c1 != c2): the split test is decided on the integer
+    D = s1 C2 - s2 C1 against per-node bounds, inside the band by the reference's f64 divisions.  Thresholds are put exactly
+    on k / (C1 C2) -- reachable values of avg1 - avg2 -- and one ulp beside them, plus the saturating cases; also rectangles
+    of zero area (average_value_in_rect returns 0.0 there, types.rs:335-338).  With DH_NO_GENERAL_INT every visit divides."""
+    forest = synth.synth_forest(7, 9, synth.FOREST_SEED_BASE + 152, rect_scale=0.08, rect_scale_max=0.7)
+    nd = forest.nodes
+    c1 = (nd["r1"][:, 2].astype(np.int64) - nd["r1"][:, 0]) * (nd["r1"][:, 3].astype(np.int64) - nd["r1"][:, 1])
+    c2 = (nd["r2"][:, 2].astype(np.int64) - nd["r2"][:, 0]) * (nd["r2"][:, 3].astype(np.int64) - nd["r2"][:, 1])
+    assert (c1 != c2).mean() > 0.5
+    cc = (np.maximum(c1, 1) * np.maximum(c2, 1)).astype(np.float64)
+    thr = nd["threshold"]
+    exact = np.round(thr * cc) / cc
+    sel = np.arange(thr.size) % 5
+    thr[sel == 0] = exact[sel == 0]
+    thr[sel == 1] = np.nextafter(exact[sel == 1], np.inf)
+    thr[sel == 2] = np.nextafter(exact[sel == 2], -np.inf)
+    thr[sel == 3] = 0.0
+    thr[11] = 65535.0; thr[12] = -65535.0; thr[13] = np.inf; thr[14] = -np.inf; thr[15] = np.nextafter(65535.0, 0.0)
+    nd["r1"][20, 2] = nd["r1"][20, 0]                  # zero-width rectangle: c1 = 0
+    nd["r2"][21, 3] = nd["r2"][21, 1]                  # zero-height rectangle: c2 = 0
+    nd["r1"][22, 2] = nd["r1"][22, 0]; nd["r2"][22, 2] = nd["r2"][22, 0]      # both empty: 0 - 0 > thr
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 240, 200
+    frames = synth.biwi_batch(3, w, h, first=37)
+    frames[1] = (frames[1] > 0) * 800                  # flat foreground: D = 0 for rectangles inside it
+    frames[2] = np.where(frames[2] > 0, 65535, 0)      # saturated sums
+    from test_gpu_parity import _check_frames
+    if not int_test:
+        os.environ["DH_NO_GENERAL_INT"] = "1"
+    try:
+        _check_frames(hp_mod, oracle, forest, model, frames.astype(np.uint16), synth.default_intrinsic(w, h), full=False)
+    finally:
+        os.environ.pop("DH_NO_GENERAL_INT", None)
+
+
+def test_general_path_patches_beyond_255_keep_the_division_walk(hp_mod, oracle):
+    """NodeG stores rectangle corners in bytes: a 300-pixel-wide patch takes the walk with the f64 divisions."""
+    sw, sh, w, h = 300, 40, 640, 120
+    forest = synth.synth_forest(4, 6, synth.FOREST_SEED_BASE + 153, patch=(sw, sh), rect_scale=0.1, rect_scale_max=0.5)
+    model = synth.ModelParams(stepwidth=8, subimage_width=sw, subimage_height=sh)
+    frames = np.stack([synth.biwi_like(640, 480, 5300 + i)[200:200 + h, :w] for i in range(2)]).copy()
+    from test_gpu_parity import _check_frames
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), full=False)
