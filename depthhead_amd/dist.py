@@ -134,10 +134,11 @@ class ShardedPredictor:
         b = 0 if self.graph else self.count % self.slots
         k = self.count % self.depth
         self.count += 1
-        if self.pending[b] is not None:
-            self.pending[b].wait()                      # stream-side wait for RCCL; the buffer is free again
-            self.pending[b] = None
         st = self.streams[k] if self.streams else stream
+        if self.pending[b] is not None:
+            with torch.cuda.stream(st):                 # the stream that is about to overwrite the buffer waits for its last gather
+                self.pending[b].wait()
+            self.pending[b] = None
         if self.graph:
             self.hp.graph_launch(st.cuda_stream)
         else:
