@@ -242,6 +242,9 @@ struct Knobs {
     int box_band = 64;                // DH_BOX_BAND
     int max_resident = 512;           // DH_MAX_RESIDENT_FRAMES
     int chunks = 0;                   // DH_CHUNKS: forked sub-batches per call; 0 = automatic (two once a call brings >= 512 frames)
+    bool no_region = false;           // DH_NO_REGION: k_cluster always gathers its first region itself
+    int region_min_hits = 0;          // DH_REGION_MIN_HITS: hit records in a frame from which k_region pre-gathers its first regions (small batches);
+                                      //   0 = automatic: 8192 for forests without leaf histogram (their rotation gather costs ~9 ns a record), 65536 with
     bool no_general_int = false;      // DH_NO_GENERAL_INT: general path with the f64 divisions on every visit
     int stage_chunk = 64;             // DH_STAGE_CHUNK: frames per upload chunk of the host entry points (copy of chunk k + 1 overlaps the kernels of chunk k)
     int host_threads = 8;             // DH_HOST_THREADS: host threads that validate / pack run-length coded payloads
@@ -263,6 +266,8 @@ static Knobs read_knobs() {
     k.box_band = std::max(1, geti("DH_BOX_BAND", 64));
     k.max_resident = std::max(1, geti("DH_MAX_RESIDENT_FRAMES", 512));
     k.chunks = std::max(0, std::min(8, geti("DH_CHUNKS", 0)));
+    k.no_region = getenv("DH_NO_REGION") != nullptr;
+    k.region_min_hits = std::max(0, geti("DH_REGION_MIN_HITS", 0));
     k.no_general_int = getenv("DH_NO_GENERAL_INT") != nullptr;
     k.stage_chunk = std::max(1, geti("DH_STAGE_CHUNK", 64));
     k.host_threads = std::max(1, std::min(64, geti("DH_HOST_THREADS", (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())))));
@@ -316,6 +321,9 @@ struct dh_predictor {
     uint32_t *leaf_hits = nullptr;   // [cap][n_leaves] rotation-vote histogram (inside `counters`), only for forests of <= DH_LEAF_HIST_MAX leaves
     size_t zero_words = 0;           // words of `counters` zeroed before every batch
     uint32_t hits_cap = 0;
+    uint32_t *pre_region = nullptr;  // [pre_cap][2][26^3] first regions of both accumulators, gathered by k_region (small batches with many hit records)
+    int pre_cap = 0;
+    uint32_t pre_min_hits = 0;       // frames with fewer hit records are gathered by k_cluster alone
     uint32_t *counters = nullptr;    // [n] hit_count | [n][400] pos_grid | [n][8000] rot_grid (one memset)
     dh_pose *ws_poses = nullptr;
     float *ws_midp = nullptr;
@@ -409,10 +417,11 @@ static void drop_graph(dh_predictor *p) {
 static void free_workspace(dh_predictor *p) {
     // a captured batch has the old workspace pointers baked in: replaying it would touch freed memory
     if (p->graph_exec) { drop_graph(p); p->graph_stale = true; }
-    void *ptrs[] = {p->box, p->win_patch, p->win_leaf, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
+    void *ptrs[] = {p->pre_region, p->box, p->win_patch, p->win_leaf, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
                     p->dbg_flags, p->dbg_guess, p->dbg_trace, p->dbg_steps, p->dbg_votes, p->dbg_vcount};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    p->pre_region = nullptr; p->pre_cap = 0;
     p->box = nullptr; p->win_patch = nullptr; p->win_leaf = nullptr; p->leaf_hits = nullptr; p->zero_words = 0;
     p->aux_leaf = nullptr; p->aux_flags = nullptr; p->aux_u32 = nullptr; p->aux_out = nullptr; p->aux_out_bytes = 0; p->aux_cap = 0;
     p->ws_frames = nullptr; p->hits = nullptr; p->hit_box = nullptr; p->hit_rot = nullptr; p->counters = nullptr; p->ws_poses = nullptr; p->ws_midp = nullptr;
@@ -676,6 +685,16 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     STEP(dev_alloc(p, &p->hits, (size_t)cap * hits_cap));
     STEP(dev_alloc(p, &p->hit_box, (size_t)cap * hits_cap));
     STEP(dev_alloc(p, &p->hit_rot, (size_t)cap * hits_cap));
+    const bool leaf_hist = p->n_leaves <= p->knobs.leaf_hist_max && !p->knobs.no_leaf_hist;
+    // k_region pays a fixed ~20 us (second initial guess, flush, launch) for spreading the first region gather over
+    // several workgroups: worth it from ~8 k hit records per frame on the rotation-record path of large forests, from
+    // ~65 k with the leaf histogram (measured: config 3 cluster 0.77 -> 0.34 ms; config 5, 38 k records per frame, would lose)
+    p->pre_min_hits = p->knobs.region_min_hits > 0 ? (uint32_t)p->knobs.region_min_hits : (leaf_hist ? 65536u : 8192u);
+    if (!p->knobs.no_region && hits_cap >= 4 * (size_t)p->pre_min_hits) {   // (a frame of this geometry can hold that many records at all)
+        // k_region serves batches of up to 128 frames (beyond that the (frame, accumulator) workgroups of k_cluster fill the chip themselves)
+        p->pre_cap = std::min(cap, 128);
+        STEP(dev_alloc(p, &p->pre_region, (size_t)p->pre_cap * 2 * DH_REGION_CELLS));
+    }
     STEP(dev_alloc(p, &p->win_patch, (size_t)cap * std::max(g.win_cap, 1)));
     STEP(dev_alloc(p, &p->win_leaf, (size_t)cap * std::max(g.win_cap, 1) * p->n_trees));
     if (g.uniform) {
@@ -684,7 +703,6 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
         if (rc == DH_OK && hipMemset(p->box, 0, words * sizeof(uint32_t)) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box)");   // the slack columns stay 0
     }
     // one block, one memset per batch: hit counters | guess grids | tile flags | window counts | leaf histogram
-    const bool leaf_hist = p->n_leaves <= p->knobs.leaf_hist_max && !p->knobs.no_leaf_hist;
     const size_t counter_words = (size_t)cap * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words + (size_t)g.tiles_x * g.tiles_y);
     STEP(dev_alloc(p, &p->counters, counter_words + (leaf_hist ? (size_t)cap * p->n_leaves : 0)));
     if (rc == DH_OK) p->leaf_hits = leaf_hist ? p->counters + counter_words : nullptr;
@@ -851,6 +869,15 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ca.guess_mask = guess_mask ? guess_mask + f0 : nullptr;
         ca.out = out + f0;
         if (p->debug) { ca.dbg_guess = p->dbg_guess; ca.dbg_trace = p->dbg_trace; ca.dbg_steps = p->dbg_steps; }
+        // few frames with many hit records each: the first region of every accumulator is gathered by several workgroups
+        const int slices = std::min(16, 256 / std::max(n, 1));
+        if (p->pre_region && slices >= 2 && f0 + n <= p->pre_cap && ca.iterations > 0) {
+            ca.pre_region = p->pre_region + (size_t)f0 * 2 * DH_REGION_CELLS;
+            ca.pre_slices = slices;
+            ca.pre_min_hits = p->pre_min_hits;
+            HIP_TRY(hipMemsetAsync(ca.pre_region, 0, (size_t)n * 2 * DH_REGION_CELLS * sizeof(uint32_t), s));
+            HIP_TRY(dh_launch_region(ca, s));
+        }
         HIP_TRY(dh_launch_cluster(ca, s));
     }
     if (profile) { HIP_TRY(hipEventRecord(p->ev[3], s)); p->ev_valid = true; }

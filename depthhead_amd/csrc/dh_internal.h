@@ -10,6 +10,7 @@
 #define DH_GRID3 8000          // 20^3
 #define DH_POSGRID 400         // 20^2
 #define DH_ROTPARTS 120
+#define DH_REGION_CELLS (26 * 26 * 26)   // k_cluster's LDS region of an accumulator (RG^3 in dh_kernels.hip)
 
 // leaf_flags bits (written by k_leaf_prepare)
 #define LF_PROB 1u   // prob > 0.0                      (prediction.rs:590)
@@ -205,6 +206,9 @@ struct ClusterArgs {
     const double  *rot_guess;  // nullable, n*3
     const uint8_t *guess_mask; // nullable, n
     dh_pose  *out;
+    uint32_t *pre_region;      // nullable [n][2][26^3]: regions around the initial guesses, gathered by k_region (zeroed per batch)
+    int       pre_slices;      // workgroups per (frame, accumulator) of k_region
+    uint32_t  pre_min_hits;    // frames with fewer hit records are left to k_cluster alone (both kernels read the same count)
     int32_t  *dbg_guess;       // nullable [n][6]
     int32_t  *dbg_trace;       // nullable [2][n][iterations+1][3]
     uint32_t *dbg_steps;       // nullable [2][n]
@@ -262,6 +266,7 @@ hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream
 hipError_t dh_launch_emit(const EmitArgs &a, hipStream_t s);
 hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s);
 hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s);
+hipError_t dh_launch_region(const ClusterArgs &a, hipStream_t s);
 hipError_t dh_launch_votes_dump(const VotesDumpArgs &a, hipStream_t s);
 hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s);
 hipError_t dh_launch_pixflags(const PixFlagArgs &a, hipStream_t s);

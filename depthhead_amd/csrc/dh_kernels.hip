@@ -1531,6 +1531,7 @@ hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
 #define CL_LIST (CL_PROD_CAP * 4) // survivors of the region gathers' bounding-box tests listed in `prod` (2048)
 #define RG 26                   // region edge; the window may sit at offsets 0..RG-20 inside it
 #define RG3 (RG * RG * RG)
+static_assert(RG3 == DH_REGION_CELLS, "dh_internal.h: DH_REGION_CELLS");
 
 // exists c in [lo,hi] and d in [0,len) with c == start + d (i32 wrapping, like the reference's
 // release-mode `pos + offset`)?
@@ -1558,22 +1559,25 @@ __device__ __forceinline__ void cluster_add_votes(const ClusterArgs &a, uint32_t
     }
 }
 
-__global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
-    __shared__ uint32_t region[RG3];
-    __shared__ __attribute__((aligned(16))) float prod[CL_PROD_CAP * 4];
-    __shared__ uint32_t cnt[CL_CHUNKS * CL_WAVES];
-    __shared__ unsigned long long red64[CL_WAVES];
-    __shared__ uint32_t red32[CL_WAVES];
-    __shared__ int32_t s_pos[3];
-    __shared__ float s_acc[4];
-    __shared__ uint32_t s_total;
+// Shared-memory carve-up of k_cluster / k_region.
+struct ClShared {
+    uint32_t *region;              // [RG3]
+    float *prod;                   // [CL_PROD_CAP * 4], doubles as the survivor list of the gathers
+    unsigned long long *red64;     // [CL_WAVES]
+    uint32_t *red32;               // [CL_WAVES]
+    int32_t *s_pos;                // [3]
+    uint32_t *s_total;
+};
 
-    const int which = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+// Initial guess of one accumulator into sh.s_pos (the caller synchronises before reading it): first strictly-greatest
+// cell, i.e. greatest value then smallest index (prediction.rs:694-702 for the 20x20 grid; :733-742 with the x-fastest
+// iteration order of meanshift.rs:114-138 for the 20^3 grid); all-zero grid -> index 0; then the caller's guesses (:437-460).
+__device__ __forceinline__ void cl_initial_guess(const ClusterArgs &a, const int which, const int frame, const ClShared sh) {
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    unsigned long long *red64 = sh.red64;
+    uint32_t *red32 = sh.red32;
+    int32_t *s_pos = sh.s_pos;
     const uint8_t gmask = a.guess_mask ? a.guess_mask[frame] : 3;
-
-    // ---------------- initial guess: first strictly-greatest cell, i.e. greatest value then smallest
-    // index (prediction.rs:694-702 for the 20x20 grid; :733-742 with the x-fastest iteration order of
-    // meanshift.rs:114-138 for the 20^3 grid); all-zero grid -> index 0
     {
         const uint32_t *g = which == 0 ? a.pos_grid + (size_t)frame * DH_POSGRID : a.rot_grid + (size_t)frame * DH_GRID3;
         const int ncell = which == 0 ? DH_POSGRID : DH_GRID3;
@@ -1629,6 +1633,143 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             }
         }
     }
+}
+
+// Adds to the (zeroed) LDS region with origin `org` every vote of accumulator `which` that falls into it, from the hit
+// records [h0, h1) of the frame -- or, for rotation votes of forests with a leaf histogram, from the leaves [l0, l1).
+// Integer atomics: exact and order-free, so any split of the ranges over workgroups sums to the same region.
+__device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which, const int frame, const int32_t org[3],
+                                          const uint32_t h0, const uint32_t h1, const uint32_t l0, const uint32_t l1, const ClShared sh) {
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    uint32_t *region = sh.region;
+    float *prod = sh.prod;
+    uint32_t &s_total = *sh.s_total;
+    const HitRec *hits = a.hits + (size_t)frame * a.hits_cap;
+    const HitBox *box = a.hit_box + (size_t)frame * a.hits_cap;
+    const HitRot *hr = a.hit_rot + (size_t)frame * a.hits_cap;
+    if (which == 0) {
+        // Two steps: (1) every thread tests the vote bounding boxes of its records against the region and
+        // appends the survivors to a list (in `prod`, idle now; a record that finds the list full is
+        // handled by its thread alone); (2) 16 lanes share each listed record and take its offset votes
+        // 16 apart, so the chain of dependent vote loads per lane is n_votes / 16 long instead of n_votes.
+        uint32_t *list = (uint32_t *)prod;
+        if (tid == 0) s_total = 0;
+        __syncthreads();
+        for (uint32_t i0 = h0; i0 < h1; i0 += CL_THREADS * 2) {        // (uniform trip count: the ballots need every lane)
+            int4 b0[2], b1[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                                   // two records' boxes in flight (64-VGPR budget)
+                const uint32_t i = min(i0 + j * CL_THREADS + tid, h1 - 1);
+                b0[j] = ((const int4 *)(box + i))[0]; b1[j] = ((const int4 *)(box + i))[1];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t i = i0 + j * CL_THREADS + tid, fc = (uint32_t)b1[j].w;
+                const bool keep = i < h1 && (fc & LF_OFF) && range_hits_span(b0[j].x, b0[j].w, org[0], RG) &&
+                                  range_hits_span(b0[j].y, b1[j].x, org[1], RG) && range_hits_span(b0[j].z, b1[j].y, org[2], RG);
+                const unsigned long long bal = __ballot(keep);             // one LDS atomic per wave, ranks from the ballot
+                uint32_t wb = 0;
+                if (lane == 0 && bal) wb = atomicAdd(&s_total, (uint32_t)__popcll(bal));
+                wb = __shfl(wb, 0);
+                if (keep) {
+                    const uint32_t slot = wb + (uint32_t)__popcll(bal & lanemask_lt());
+                    if (slot < CL_LIST) list[slot] = i;
+                    else cluster_add_votes(a, region, hits, box, i, 0u, 1u, org);   // list full: this thread takes the record alone
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t np = min(s_total, (uint32_t)CL_LIST);
+        for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) cluster_add_votes(a, region, hits, box, list[k >> 4], k & 15u, 16u, org);
+        __syncthreads();
+    } else if (a.leaf_hits) {
+        // Rotation votes depend only on the leaf (prediction.rs:601-636): the accumulator is
+        // sum over leaves of (times the leaf voted) x (its distinct cells), so the gather walks
+        // the leaves that voted at all instead of every hit -- u32 wrap-around makes
+        // hits * v * mult the same residue as that many separate adds.
+        const uint32_t *lh = a.leaf_hits + (size_t)frame * a.f.n_leaves;
+        uint32_t *list = (uint32_t *)prod;                    // same two-step scheme as the position gather
+        for (uint32_t c0 = l0; c0 < l1; c0 += CL_LIST) {
+            if (tid == 0) s_total = 0;
+            __syncthreads();
+            const uint32_t c1 = min(l1, c0 + CL_LIST);
+            for (uint32_t l0 = c0; l0 < c1; l0 += CL_THREADS) {          // (uniform trip count: the ballot needs every lane)
+                const uint32_t l = l0 + tid;
+                bool keep = false;
+                if (l < c1 && lh[l]) {
+                    const uint4 t2 = ((const uint4 *)(a.f.tpl + l))[2];
+                    const uint32_t bl = t2.y, bh = t2.z;
+                    keep = bl != 0xFFFFFFFFu && range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG) &&
+                           range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG) &&
+                           range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG);
+                }
+                const unsigned long long bal = __ballot(keep);             // one LDS atomic per wave, ranks from the ballot
+                uint32_t wb = 0;
+                if (lane == 0 && bal) wb = atomicAdd(&s_total, (uint32_t)__popcll(bal));
+                wb = __shfl(wb, 0);
+                if (keep) list[wb + (uint32_t)__popcll(bal & lanemask_lt())] = l;
+            }
+            __syncthreads();
+            const uint32_t np = s_total;
+            for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) {
+                const uint32_t l = list[k >> 4], sub = k & 15u;
+                const uint4 *tp = (const uint4 *)(a.f.tpl + l);
+                const uint4 t1 = tp[1], t2 = tp[2], t3 = tp[3];
+                const uint32_t v = lh[l] * t1.z, q1 = t2.w + (t3.x & 0xffffu);   // times the leaf voted x valtoadd
+                for (uint32_t q = t2.w + sub; q < q1; q += 16u) {
+                    const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                  // prediction.rs:635
+                    uint32_t dx = (b & 255u) - (uint32_t)org[0];
+                    uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
+                    uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
+                    if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        for (uint32_t i0 = h0; i0 < h1; i0 += CL_THREADS * 2) {
+            uint4 r[2];
+            uint32_t vv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t i = i0 + j * CL_THREADS + tid;
+                r[j].x = 0xFFFFFFFFu;
+                if (i < h1) { r[j] = *(const uint4 *)(hr + i); vv[j] = box[i].v; }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t bl = r[j].x, bh = r[j].y;
+                if (bl == 0xFFFFFFFFu) continue;
+                if (!range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG)) continue;
+                if (!range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG)) continue;
+                if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG)) continue;
+                const uint32_t v = vv[j];
+                for (uint32_t q = r[j].z; q < r[j].z + (r[j].w & 0xffffu); ++q) {
+                    const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                   // prediction.rs:635
+                    uint32_t dx = (b & 255u) - (uint32_t)org[0];
+                    uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
+                    uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
+                    if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
+    __shared__ uint32_t region[RG3];
+    __shared__ __attribute__((aligned(16))) float prod[CL_PROD_CAP * 4];
+    __shared__ uint32_t cnt[CL_CHUNKS * CL_WAVES];
+    __shared__ unsigned long long red64[CL_WAVES];
+    __shared__ uint32_t red32[CL_WAVES];
+    __shared__ int32_t s_pos[3];
+    __shared__ float s_acc[4];
+    __shared__ uint32_t s_total;
+
+    const int which = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+
+    const ClShared sh{region, prod, red64, red32, s_pos, &s_total};
+    cl_initial_guess(a, which, frame, sh);
     __syncthreads();
     int32_t pos[3] = {s_pos[0], s_pos[1], s_pos[2]};
     if (a.dbg_guess && tid < 3) a.dbg_guess[(size_t)frame * 6 + which * 3 + tid] = pos[tid];
@@ -1639,9 +1780,6 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
     // ---------------- mean shift (meanshift.rs:328-407)
     uint32_t n_hits = a.hit_count[frame];
     if (n_hits > a.hits_cap) n_hits = a.hits_cap;
-    const HitRec *hits = a.hits + (size_t)frame * a.hits_cap;
-    const HitBox *box = a.hit_box + (size_t)frame * a.hits_cap;
-    const HitRot *hr = a.hit_rot + (size_t)frame * a.hits_cap;
     int32_t org[3] = {0, 0, 0};     // region origin (cell coordinates of region[0])
     bool have_region = false;
     uint32_t steps = 0;
@@ -1655,114 +1793,14 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             wo0 = wo1 = wo2 = (RG - 20) / 2;
             have_region = true;
             __syncthreads();                       // previous iteration's readers are done
-            for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
-            __syncthreads();
-            if (which == 0) {
-                // Two steps: (1) every thread tests the vote bounding boxes of its records against the region and
-                // appends the survivors to a list (in `prod`, idle now; a record that finds the list full is
-                // handled by its thread alone); (2) 16 lanes share each listed record and take its offset votes
-                // 16 apart, so the chain of dependent vote loads per lane is n_votes / 16 long instead of n_votes.
-                uint32_t *list = (uint32_t *)prod;
-                if (tid == 0) s_total = 0;
-                __syncthreads();
-                for (uint32_t i0 = 0; i0 < n_hits; i0 += CL_THREADS * 2) {        // (uniform trip count: the ballots need every lane)
-                    int4 b0[2], b1[2];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {                                   // two records' boxes in flight (64-VGPR budget)
-                        const uint32_t i = min(i0 + j * CL_THREADS + tid, n_hits - 1);
-                        b0[j] = ((const int4 *)(box + i))[0]; b1[j] = ((const int4 *)(box + i))[1];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const uint32_t i = i0 + j * CL_THREADS + tid, fc = (uint32_t)b1[j].w;
-                        const bool keep = i < n_hits && (fc & LF_OFF) && range_hits_span(b0[j].x, b0[j].w, org[0], RG) &&
-                                          range_hits_span(b0[j].y, b1[j].x, org[1], RG) && range_hits_span(b0[j].z, b1[j].y, org[2], RG);
-                        const unsigned long long bal = __ballot(keep);             // one LDS atomic per wave, ranks from the ballot
-                        uint32_t wb = 0;
-                        if (lane == 0 && bal) wb = atomicAdd(&s_total, (uint32_t)__popcll(bal));
-                        wb = __shfl(wb, 0);
-                        if (keep) {
-                            const uint32_t slot = wb + (uint32_t)__popcll(bal & lanemask_lt());
-                            if (slot < CL_LIST) list[slot] = i;
-                            else cluster_add_votes(a, region, hits, box, i, 0u, 1u, org);   // list full: this thread takes the record alone
-                        }
-                    }
-                }
-                __syncthreads();
-                const uint32_t np = min(s_total, (uint32_t)CL_LIST);
-                for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) cluster_add_votes(a, region, hits, box, list[k >> 4], k & 15u, 16u, org);
-                __syncthreads();
-            } else if (a.leaf_hits) {
-                // Rotation votes depend only on the leaf (prediction.rs:601-636): the accumulator is
-                // sum over leaves of (times the leaf voted) x (its distinct cells), so the gather walks
-                // the leaves that voted at all instead of every hit -- u32 wrap-around makes
-                // hits * v * mult the same residue as that many separate adds.
-                const uint32_t *lh = a.leaf_hits + (size_t)frame * a.f.n_leaves;
-                uint32_t *list = (uint32_t *)prod;                    // same two-step scheme as the position gather
-                for (uint32_t c0 = 0; c0 < a.f.n_leaves; c0 += CL_LIST) {
-                    if (tid == 0) s_total = 0;
-                    __syncthreads();
-                    const uint32_t c1 = min(a.f.n_leaves, c0 + CL_LIST);
-                    for (uint32_t l0 = c0; l0 < c1; l0 += CL_THREADS) {          // (uniform trip count: the ballot needs every lane)
-                        const uint32_t l = l0 + tid;
-                        bool keep = false;
-                        if (l < c1 && lh[l]) {
-                            const uint4 t2 = ((const uint4 *)(a.f.tpl + l))[2];
-                            const uint32_t bl = t2.y, bh = t2.z;
-                            keep = bl != 0xFFFFFFFFu && range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG) &&
-                                   range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG) &&
-                                   range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG);
-                        }
-                        const unsigned long long bal = __ballot(keep);             // one LDS atomic per wave, ranks from the ballot
-                        uint32_t wb = 0;
-                        if (lane == 0 && bal) wb = atomicAdd(&s_total, (uint32_t)__popcll(bal));
-                        wb = __shfl(wb, 0);
-                        if (keep) list[wb + (uint32_t)__popcll(bal & lanemask_lt())] = l;
-                    }
-                    __syncthreads();
-                    const uint32_t np = s_total;
-                    for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) {
-                        const uint32_t l = list[k >> 4], sub = k & 15u;
-                        const uint4 *tp = (const uint4 *)(a.f.tpl + l);
-                        const uint4 t1 = tp[1], t2 = tp[2], t3 = tp[3];
-                        const uint32_t v = lh[l] * t1.z, q1 = t2.w + (t3.x & 0xffffu);   // times the leaf voted x valtoadd
-                        for (uint32_t q = t2.w + sub; q < q1; q += 16u) {
-                            const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                  // prediction.rs:635
-                            uint32_t dx = (b & 255u) - (uint32_t)org[0];
-                            uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
-                            uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
-                            if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
-                        }
-                    }
-                    __syncthreads();
-                }
+            if (a.pre_region && it == 0 && n_hits >= a.pre_min_hits) {
+                // the region around the initial guess was gathered by k_region (several workgroups per frame)
+                const uint32_t *pr = a.pre_region + ((size_t)frame * 2 + which) * RG3;
+                for (int i = tid; i < RG3; i += CL_THREADS) region[i] = pr[i];
             } else {
-                for (uint32_t i0 = 0; i0 < n_hits; i0 += CL_THREADS * 2) {
-                    uint4 r[2];
-                    uint32_t vv[2];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        uint32_t i = i0 + j * CL_THREADS + tid;
-                        r[j].x = 0xFFFFFFFFu;
-                        if (i < n_hits) { r[j] = *(const uint4 *)(hr + i); vv[j] = box[i].v; }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const uint32_t bl = r[j].x, bh = r[j].y;
-                        if (bl == 0xFFFFFFFFu) continue;
-                        if (!range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG)) continue;
-                        if (!range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG)) continue;
-                        if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG)) continue;
-                        const uint32_t v = vv[j];
-                        for (uint32_t q = r[j].z; q < r[j].z + (r[j].w & 0xffffu); ++q) {
-                            const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                   // prediction.rs:635
-                            uint32_t dx = (b & 255u) - (uint32_t)org[0];
-                            uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
-                            uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
-                            if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
-                        }
-                    }
-                }
+                for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
+                __syncthreads();
+                cl_gather(a, which, frame, org, 0u, n_hits, 0u, a.f.n_leaves, sh);
             }
         }
         __syncthreads();
@@ -1871,6 +1909,55 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
 hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s) {
     if (a.n_frames == 0) return hipSuccess;
     hipLaunchKernelGGL(k_cluster, dim3(2, a.n_frames), dim3(CL_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+// ================================================================== k_region
+// The first region gather of k_cluster, spread over several workgroups per (frame, accumulator): with few frames in the
+// batch and many hit records per frame (large forests, stride 1-2: 60-90 k records per frame at BASELINE config 3) one
+// workgroup streaming a whole frame's records is the slowest thing in the step while most CUs idle.  Workgroup
+// (slice, frame, which) recomputes the initial guess (a few microseconds), gathers its share of the records (or leaves)
+// into an LDS region exactly as k_cluster would and adds its non-zero cells to the frame's pre-built region in global
+// memory (integer atomics: the sum over the slices is the region k_cluster would have built).
+__global__ void __launch_bounds__(CL_THREADS, 8) k_region(ClusterArgs a) {
+    __shared__ uint32_t region[RG3];
+    __shared__ __attribute__((aligned(16))) float prod[CL_PROD_CAP * 4];
+    __shared__ unsigned long long red64[CL_WAVES];
+    __shared__ uint32_t red32[CL_WAVES];
+    __shared__ int32_t s_pos[3];
+    __shared__ uint32_t s_total;
+    const int slice = blockIdx.x, frame = blockIdx.y, which = blockIdx.z, tid = threadIdx.x;
+    const ClShared sh{region, prod, red64, red32, s_pos, &s_total};
+    uint32_t n_hits = a.hit_count[frame];
+    if (n_hits > a.hits_cap) n_hits = a.hits_cap;
+    if (n_hits < a.pre_min_hits) return;                            // few records: k_cluster gathers this frame's regions itself
+    // this workgroup's share: hit records in whole rounds of the gather loops, leaves in whole list chunks
+    const uint32_t S = (uint32_t)a.pre_slices;
+    const uint32_t hper = ((n_hits + S - 1) / S + 2 * CL_THREADS - 1) / (2 * CL_THREADS) * (2 * CL_THREADS);
+    const uint32_t h0 = min(n_hits, (uint32_t)slice * hper), h1 = min(n_hits, h0 + hper);
+    const uint32_t lper = ((a.f.n_leaves + S - 1) / S + CL_LIST - 1) / CL_LIST * CL_LIST;
+    const uint32_t l0 = min(a.f.n_leaves, (uint32_t)slice * lper), l1 = min(a.f.n_leaves, l0 + lper);
+    const bool by_leaves = which == 1 && a.leaf_hits;
+    if (by_leaves ? l0 >= l1 : h0 >= h1) return;                    // nothing in this share (uniform for the workgroup)
+    cl_initial_guess(a, which, frame, sh);
+    __syncthreads();
+    int32_t org[3];
+    for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)s_pos[k] - 10u - (uint32_t)((RG - 20) / 2));
+    for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
+    __syncthreads();
+    cl_gather(a, which, frame, org, h0, h1, l0, l1, sh);
+    __syncthreads();
+    uint32_t *pr = a.pre_region + ((size_t)frame * 2 + which) * RG3;
+    for (int i = tid; i < RG3; i += CL_THREADS) {
+        const uint32_t v = region[i];
+        if (v) atomicAdd(&pr[i], v);
+    }
+}
+
+hipError_t dh_launch_region(const ClusterArgs &a, hipStream_t s) {
+    if (a.n_frames == 0 || a.iterations == 0 || !a.pre_region || a.pre_slices < 1) return hipSuccess;
+    if (a.n_frames > 65535) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_region, dim3(a.pre_slices, a.n_frames, 2), dim3(CL_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

@@ -435,3 +435,32 @@ def test_general_path_patches_beyond_255_keep_the_division_walk(hp_mod, oracle):
     frames = np.stack([synth.biwi_like(640, 480, 5300 + i)[200:200 + h, :w] for i in range(2)]).copy()
     from test_gpu_parity import _check_frames
     _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), full=False)
+
+
+@pytest.mark.parametrize("min_hits", [None, "1", "100000000"])
+@pytest.mark.parametrize("leaf_hist", [True, False])
+def test_first_regions_gathered_by_k_region(hp_mod, oracle, leaf_hist, min_hits):
+    """Small batches with many hit records: k_region gathers the first mean-shift region of both accumulators with several
+    workgroups per frame and k_cluster starts from it.  Forced on for every frame (DH_REGION_MIN_HITS=1), off (huge
+    threshold) and automatic, with and without the leaf histogram: identical traces and poses (integer atomics are order-free)."""
+    forest = synth.fit_forest(8, 10, synth.FOREST_SEED_BASE + 61, n_frames=12, subset=1500)
+    model = synth.ModelParams(stepwidth=2)
+    w, h = 320, 240
+    frames = synth.biwi_batch(5, w, h, first=90)
+    frames[4] = 0                                                     # a frame without any hit record
+    env = {}
+    if min_hits is not None:
+        env["DH_REGION_MIN_HITS"] = min_hits
+    if not leaf_hist:
+        env["DH_NO_LEAF_HIST"] = "1"
+    os.environ.update(env)
+    try:
+        from test_gpu_parity import _check_frames
+        _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), full=False)
+        rs = np.random.RandomState(4)
+        _check_frames(hp_mod, oracle, forest, model, frames[:3], synth.default_intrinsic(w, h),
+                      rs.uniform(-100, 900, (3, 3)).astype(np.float32), rs.uniform(-1, 1, (3, 3)), np.array([3, 1, 2], dtype=np.uint8), full=False)
+        _product_mode_check(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h))
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
