@@ -232,6 +232,10 @@ def main():
                 "traffic_source": prof.source if traffic is not None else None, "profile_head": prof.head,
                 "profile_matches_build": prof.matches, "kernel_source_sha256_16": prof.build_hash,
                 "algorithmic_bytes_per_launch": b_alg, "launch_ms": round(acc[dom], 4),
+                "launch_ms_is": "the kernel's duration with ONE batch in flight (HIP events around every kernel of a dedicated pass, "
+                                "as in profiles/*_kernel_stats.csv = rocprofv3 --stats of `bench.py --pipeline 1`); in the timed region "
+                                f"{depth} batches are in flight and kernels of consecutive batches share the chip "
+                                "(profiles/*_kernel_stats_2inflight.csv)",
                 # the same algorithmic bytes over the whole step (all five kernels): what the job as a whole reaches
                 "whole_step_frac": round(b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
                 "note": "achieved = algorithmic bytes of the launch / duration of the dominant kernel (live HIP events). "

@@ -16,15 +16,21 @@ export TMPDIR=/tmp
 cd /tmp
 python3 "$REPO/bench.py" --steps 20 --warmup 3 $EXTRA > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 echo "bench done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extras $EXTRA > "$OUT/${TAG}_stats.log" 2>&1
+# Per-kernel durations: ONE batch in flight (--pipeline 1), so that a launch's duration is that kernel's own time -- the figure
+# bench.py's roofline uses (its HIP-event pass also runs one predictor alone).  With the default two batches in flight
+# kernels of consecutive batches share the chip and every launch takes longer while two run at once; that trace is kept
+# beside it (*_kernel_stats_2inflight.csv) for the record.
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extras --pipeline 1 $EXTRA > "$OUT/${TAG}_stats.log" 2>&1
 cp "$(ls "$OUT/${TAG}_stats"/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_kernel_stats.csv"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats2" -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extras $EXTRA > "$OUT/${TAG}_stats2.log" 2>&1
+cp "$(ls "$OUT/${TAG}_stats2"/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_kernel_stats_2inflight.csv"
 echo "stats done"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc$i" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras $EXTRA > "$OUT/${TAG}_pmc$i.log" 2>&1 || echo "pmc group $i failed: $grp"
+  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc$i" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pipeline 1 $EXTRA > "$OUT/${TAG}_pmc$i.log" 2>&1 || echo "pmc group $i failed: $grp"
   echo "pmc group $i done"
 done
 cd "$REPO"
@@ -57,6 +63,7 @@ for k, d in acc.items():
 head_file = os.path.join(root, ".git_head")      # written by tools/gpu.sh before the snapshot leaves (the box has no .git)
 meta = {"tag": tag, "kernel_source_sha256_16": kernel_hash(),
         "git_head": open(head_file).read().strip() if os.path.exists(head_file) else None,
+        "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pipeline 1",
         "note": "averages per launch over the bench's launches; FETCH_SIZE is in KB and under-reports wide reads by 2x on gfx950 "
                 "(MI355X_MICROARCH.md, HBM); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves"}
 mem["_meta"] = meta
