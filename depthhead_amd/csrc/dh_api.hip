@@ -738,7 +738,7 @@ extern "C" int dh_predictor_reserve(dh_predictor *p, int n, int w, int h) {
     return reserve(p, n, w, h);
 }
 
-// Enqueue the three kernels for frames [f0, f0 + n) of the batch on stream s.
+// Enqueue the kernels (k_boxsum / k_pixflags, k_traverse, k_emit, k_vote, [k_region,] k_cluster) for frames [f0, f0 + n) of the batch on stream s.
 static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n, int w, int h, const float K[9],
                          const float kinv[9], const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
                          dh_pose *out, hipStream_t s, bool profile, int32_t *leaf_out = nullptr, uint8_t *flags_out = nullptr,

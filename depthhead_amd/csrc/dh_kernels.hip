@@ -1,14 +1,19 @@
 // dh_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4: wave64, 160 KB LDS/CU).
 //
 // The hot path of depthhead's HoughPrediction::predict_parameter_parallel
-// (/root/reference src/hough/prediction.rs:397-753) as four kernels:
+// (/root/reference src/hough/prediction.rs:397-753):
 //
 //   k_leaf_prepare  once per forest: everything that depends only on a leaf (vote weight, both
-//                   covariance gates, rotation bins, vote bounding boxes)
-//   k_traverse      per batch: summed-area-table tile in LDS -> background gate -> root->leaf walk
-//                   of every (patch, tree) -> probability gate -> (patch, leaf) hit records
+//                   covariance gates, rotation bins, vote bounding boxes); k_nodes_compact: integer split bounds
+//   k_boxsum        per batch (uniform-rectangle forests): image of all rectangle sums of a frame, tile flags
+//   k_traverse      per batch: tile of window positions -> region of the rectangle-sum image (or a summed-area
+//                   table) in LDS -> background gate -> root->leaf walk of every (window, tree) -> window list
+//   k_emit          per batch: probability gate in tree order -> (window, leaf) hit records, leaf histogram
 //   k_vote          per batch: coarse 20x20 / 20^3 guess grids from the hit records
+//   k_region        small batches with many hit records: first mean-shift regions gathered by several workgroups
 //   k_cluster       per batch: initial guesses + both fixed-iteration Gaussian mean shifts -> pose
+//   k_mask, k_hough2d, k_blur_u16, k_argmax2d: the sibling consumers (predict_mask, 2-D Hough variant);
+//   k_rle_decode: BIWI run-length coded depth payloads -> frames
 //
 // No MFMA anywhere: there is no dense contraction on this path.  All integer work is exact and
 // order-free (u32 wrapping adds); every floating-point expression is evaluated in the reference's
