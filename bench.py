@@ -172,6 +172,24 @@ def main():
             acc[k] += tm[k] / reps
     hp.set_profiling(False)
     torch.cuda.synchronize(dev)
+    # the same events with `depth` batches in flight (one launch per predictor, started together, a few rounds): kernels of
+    # consecutive batches share the chip, so every launch takes longer while several run at once
+    acc_fl = None
+    if depth > 1:
+        acc_fl = {k: 0.0 for k in acc}
+        rounds = 4
+        for q in hps:
+            q.set_profiling(True)
+        for _ in range(rounds):
+            for k, q in enumerate(hps):
+                q.predict_batch_device(frames.data_ptr(), NF, W, H, intr, sp.pose_bufs[k % sp.slots].data_ptr(), stream=sp.streams[k].cuda_stream)
+            torch.cuda.synchronize(dev)
+            for q in hps:
+                tm = q.timing()
+                for k in acc_fl:
+                    acc_fl[k] += tm[k] / (rounds * depth)
+        for q in hps:
+            q.set_profiling(False)
 
     # ---- PCIe-inclusive rate: the same batch through the host-buffer entry point (H2D copy of the
     # frames, compute, D2H of the poses).  Reported next to `value`, never as `value`.
@@ -275,6 +293,7 @@ def main():
             "roofline": roof,
             "repeat_ms_per_step": [round(r, 4) for r in repeats],
             "kernels_ms": kernels,
+            "kernels_ms_in_flight": None if acc_fl is None else {k: round(v, 4) for k, v in acc_fl.items()},   # per launch, `batches_in_flight` at once
             # measured HBM traffic (PMC, gfx950-corrected) over the live duration of every kernel: shows which
             # kernel actually runs at memory speed (k_boxsum) and which are latency / issue bound
             "kernels_hbm": {KERNEL_OF[k]: {"traffic": t, "GB/s": round(t / (acc[k] * 1e-3) / 1e9, 1), "frac": round(t / (acc[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
