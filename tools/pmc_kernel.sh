@@ -11,7 +11,7 @@ i=0
 for grp in "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM"; do
   i=$((i+1))
-  timeout -k 10 180 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$REPO/$OUT/p$i" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$REPO/$OUT/p$i.log" 2>&1 || echo "group $i failed: $grp"
+  timeout -k 10 180 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$REPO/$OUT/p$i" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras --pipeline 1 > "$REPO/$OUT/p$i.log" 2>&1 || echo "group $i failed: $grp"
 done
 cd "$REPO"
 python3 - "$OUT" <<'PY'

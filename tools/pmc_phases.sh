@@ -2,14 +2,17 @@
 # Per-phase instruction counts of k_traverse: the kernel is cut short after phase N (DH_TRAV_STOP, a
 # diagnostic switch) and the SQ counters of the truncated runs are differenced.
 # Usage (GPU box, repo root): bash tools/pmc_phases.sh gpurun_out/ph
+# Needs the profiling twin of the library (the product library has these switches compiled out):
+#   python -m depthhead_amd.build --knobs
 set -e
 OUT=${1:-gpurun_out/ph}
 REPO=$(pwd)
+export DH_LIB_PATH=$REPO/depthhead_amd/libdepthhead_hip_knobs.so
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for st in 9 1 3 0; do
-  DH_TRAV_STOP=$st timeout -k 10 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$REPO/$OUT/s$st" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$REPO/$OUT/s$st.log" 2>&1 || echo "stop $st failed"
+  DH_TRAV_STOP=$st timeout -k 10 180 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$REPO/$OUT/s$st" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras --pipeline 1 > "$REPO/$OUT/s$st.log" 2>&1 || echo "stop $st failed"
 done
 cd "$REPO"
 python3 - "$OUT" <<'PY'

@@ -14,7 +14,7 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM" \
            "SQ_INSTS_VALU_MFMA_I8 SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_INSTS_BRANCH"; do
   i=$((i+1))
-  timeout -k 10 180 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$REPO/$OUT/p$i" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$REPO/$OUT/p$i.log" 2>&1 || echo "group $i failed: $grp"
+  timeout -k 10 180 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$REPO/$OUT/p$i" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras --pipeline 1 > "$REPO/$OUT/p$i.log" 2>&1 || echo "group $i failed: $grp"
 done
 cd "$REPO"
 python3 - "$OUT" <<'PY'
