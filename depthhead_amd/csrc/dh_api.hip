@@ -704,7 +704,7 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     }
     // one block, one memset per batch: hit counters | guess grids | tile flags | window counts | leaf histogram
     const size_t counter_words = (size_t)cap * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words + (size_t)g.tiles_x * g.tiles_y);
-    STEP(dev_alloc(p, &p->counters, counter_words + (leaf_hist ? (size_t)cap * p->n_leaves : 0)));
+    STEP(dev_alloc(p, &p->counters, counter_words + (leaf_hist ? (size_t)cap * p->n_leaves : 0) + 4));   // (+4: the zero-fill kernel rounds up to 16 bytes)
     if (rc == DH_OK) p->leaf_hits = leaf_hist ? p->counters + counter_words : nullptr;
     p->zero_words = counter_words + (leaf_hist ? (size_t)cap * p->n_leaves : 0);
     STEP(dev_alloc(p, &p->ws_poses, cap));
@@ -875,7 +875,8 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
             ca.pre_region = p->pre_region + (size_t)f0 * 2 * DH_REGION_CELLS;
             ca.pre_slices = slices;
             ca.pre_min_hits = p->pre_min_hits;
-            HIP_TRY(hipMemsetAsync(ca.pre_region, 0, (size_t)n * 2 * DH_REGION_CELLS * sizeof(uint32_t), s));
+            if (p->capturing) HIP_TRY(dh_launch_zero(ca.pre_region, (size_t)n * 2 * DH_REGION_CELLS * sizeof(uint32_t), s));
+            else HIP_TRY(hipMemsetAsync(ca.pre_region, 0, (size_t)n * 2 * DH_REGION_CELLS * sizeof(uint32_t), s));
             HIP_TRY(dh_launch_region(ca, s));
         }
         HIP_TRY(dh_launch_cluster(ca, s));
@@ -905,7 +906,9 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
     mat3_inv_f32(K, kinv);   // cached in a RefCell by the reference (types.rs:436-441)
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
-        HIP_TRY(hipMemsetAsync(p->counters, 0, p->zero_words * sizeof(uint32_t), s));
+        // (inside a captured graph the zero-fill is a kernel node: see k_zero)
+        if (p->capturing) HIP_TRY(dh_launch_zero(p->counters, (p->zero_words * sizeof(uint32_t) + 15) & ~(size_t)15, s));
+        else HIP_TRY(hipMemsetAsync(p->counters, 0, p->zero_words * sizeof(uint32_t), s));
         const uint16_t *fr = frames + (size_t)f0 * w * h;
         const float *mg = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
         const double *rg = rot_guess ? rot_guess + (size_t)f0 * 3 : nullptr;

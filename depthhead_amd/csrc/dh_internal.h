@@ -257,6 +257,7 @@ struct Mat3Arg { float m[9]; };
 hipError_t dh_launch_blur_u16(const uint16_t *in, uint16_t *tmp, uint16_t *out, int n, int w, int h, const float *kern, int klen, hipStream_t s);
 hipError_t dh_launch_argmax2d(const uint16_t *hough, const uint16_t *frames, int n, int w, int h, const float kinv[9], dh_pose *out, hipStream_t s);
 hipError_t dh_launch_rle_decode(const RleArgs &a, hipStream_t s);
+hipError_t dh_launch_zero(void *ptr, size_t bytes, hipStream_t s);   // ptr, bytes multiples of 16
 hipError_t dh_launch_mask(const AuxArgs &a, hipStream_t s);
 hipError_t dh_launch_hough2d(const AuxArgs &a, uint16_t *out, hipStream_t s);
 hipError_t dh_kernels_init();

@@ -21,6 +21,8 @@
 // bit-identical to the CPU restatement in oracle/.
 #include "dh_internal.h"
 
+#include <algorithm>
+
 #define WAVE 64
 
 // Per-phase profiling switches (kernels cut short after phase N: results INVALID) exist only in builds with
@@ -2196,5 +2198,23 @@ hipError_t dh_launch_argmax2d(const uint16_t *hough, const uint16_t *frames, int
     Mat3Arg k;
     for (int i = 0; i < 9; ++i) k.m[i] = kinv[i];
     hipLaunchKernelGGL(k_argmax2d, dim3(n), dim3(1024), 0, s, hough, frames, w, h, k, out);
+    return hipGetLastError();
+}
+
+// ================================================================== k_zero
+// Zero-fill of the per-batch counters inside a captured hipGraph: a memset node of tens of megabytes was observed to
+// leave part of the range untouched on replay (ROCm 7.2; tools/soak.py found poses going wrong from the second replay of a
+// graph captured on a 512-frame workspace), a kernel node does what it says.
+__global__ void __launch_bounds__(256) k_zero(uint4 *p, size_t n16) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = z;
+}
+
+hipError_t dh_launch_zero(void *ptr, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if ((((size_t)ptr) | bytes) & 15) return hipErrorInvalidValue;
+    const size_t n16 = bytes / 16;
+    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_zero, dim3(blocks), dim3(256), 0, s, (uint4 *)ptr, n16);
     return hipGetLastError();
 }

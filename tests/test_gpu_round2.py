@@ -464,3 +464,38 @@ def test_first_regions_gathered_by_k_region(hp_mod, oracle, leaf_hist, min_hits)
     finally:
         for k in env:
             os.environ.pop(k, None)
+
+
+def test_graph_replays_on_a_large_workspace(hp_mod, oracle):
+    """Found by tools/soak.py: a graph captured on a workspace sized for 512 frames zero-fills 22 MB of per-batch counters per
+    replay; as a memset NODE that fill left part of the range untouched from the second replay on (stale window counts and
+    histograms -> wrong poses).  The fill is a kernel node now.  Several replays on new contents, also with k_region."""
+    torch = pytest.importorskip("torch")
+    from depthhead_amd._lib import POSE_DTYPE
+    forest = synth.fit_forest(10, 12, synth.FOREST_SEED_BASE + 71, n_frames=12, subset=2000)
+    model = synth.ModelParams(stepwidth=4)
+    w, h, n = 640, 480, 2
+    K = synth.default_intrinsic(w, h)
+    intr = hp_mod.IntrinsicMatrix(K)
+    dev = torch.device("cuda:0")
+    frames = synth.biwi_batch(8, w, h, first=120)
+    frames[3] = 0
+    ref = oracle.predict_batch(forest, model, frames, K)
+    fr = torch.zeros((n, h, w), dtype=torch.int16, device=dev)
+    out = torch.zeros(n * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev)
+    for env in ({}, {"DH_REGION_MIN_HITS": "1", "DH_NO_LEAF_HIST": "1"}):
+        os.environ.update(env)
+        try:
+            with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+                hp.reserve(512, w, h)
+                hp.graph_capture(fr.data_ptr(), n, w, h, intr, out.data_ptr())
+                for a, b in ((0, 1), (2, 3), (3, 3), (4, 5), (0, 7), (6, 6)):
+                    fr.copy_(torch.from_numpy(frames[[a, b]].view(np.int16)))
+                    hp.graph_launch(st.cuda_stream)
+                    st.synchronize()
+                    poses = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)
+                    assert _poses_equal(poses, ref[[a, b]]), (a, b, env)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
