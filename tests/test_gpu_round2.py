@@ -499,3 +499,54 @@ def test_graph_replays_on_a_large_workspace(hp_mod, oracle):
         finally:
             for k in env:
                 os.environ.pop(k, None)
+
+
+def test_error_behaviour_of_the_round2_entry_points(hp_mod, hip_lib):
+    """Status codes, never a fault: empty and NULL arguments, frames smaller than the patch, an output buffer that is too
+    small, sizes that do not fit -- for the entry points added in round 2."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    from depthhead_amd import biwi
+    from depthhead_amd._lib import DepthheadError, pinned_empty
+    forest = synth.synth_forest(3, 5, 31)
+    model = synth.ModelParams(stepwidth=4)
+    K = hp_mod.IntrinsicMatrix(synth.default_intrinsic(160, 120))
+    frames = synth.biwi_batch(2, 160, 120)
+    pay = [biwi.encode_depth(f) for f in frames]
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        assert hp.predict_batch_rle([], K).shape == (0,)                                   # empty batch
+        assert hp.predict_parameter_from2dhough(np.zeros((0, 120, 160), np.uint16), K).shape == (0,)
+        assert hp.build_hough_image(np.zeros((0, 120, 160), np.uint16), K).shape == (0, 120, 160)
+        with pytest.raises(DepthheadError) as ei:
+            hp.predict_parameter_from2dhough(np.zeros((1, 60, 160), np.uint16), K)        # shorter than the patch
+        assert ei.value.code == -5
+        with pytest.raises(DepthheadError) as ei:
+            hp.predict_batch_rle([biwi.encode_depth(np.zeros((60, 160), np.uint16))], K)   # decodes to a frame shorter than the patch
+        assert ei.value.code == -5
+        dev = torch.zeros((2, 120, 160), dtype=torch.int16, device="cuda:0")
+        with pytest.raises(DepthheadError) as ei:
+            hp.decode_depth_device(pay, dev.data_ptr(), 2 * 120 * 160 - 1)                 # output one pixel short
+        assert ei.value.code == -1
+        huge = struct.pack("<II", 70000, 70000) + struct.pack("<II", 0, 0)
+        with pytest.raises(DepthheadError) as ei:
+            hp.decode_depth_device([huge])                                                  # 4.9 G pixels: refused, not allocated
+        assert ei.value.code == -5
+        zero = struct.pack("<II", 0, 17)
+        with pytest.raises(DepthheadError):
+            hp.decode_depth_device([zero])
+        # raw NULLs through the C ABI
+        assert hip_lib.dh_predict_batch_rle(hp._ph, None, None, 1, None, None, None, None, None) == -1
+        assert hip_lib.dh_predict_from2dhough(hp._ph, None, 1, 160, 120, None, None) == -1
+        assert hip_lib.dh_build_hough_image(None, None, 1, 160, 120, None, None) == -1
+        assert hip_lib.dh_biwi_decode_depth_device(hp._ph, None, None, 1, None, C.c_size_t(0), None, None) == -1
+        assert hip_lib.dh_host_alloc(C.c_size_t(16), None) == -1
+        assert hip_lib.dh_host_free(None) == 0
+        assert hip_lib.dh_predict_batch_rle(hp._ph, None, None, -3, None, None, None, None, None) == -1
+        # and the predictor still works
+        ok = hp.predict_batch_rle(pay, K)
+        assert ok.tobytes() == hp.predict_batch(frames, K).tobytes()
+    small = pinned_empty((0,), np.uint16)
+    assert small.size == 0
+
+
+import struct  # noqa: E402  (used by the test above)
