@@ -106,6 +106,13 @@ def main():
     distinct = synth.biwi_batch(nd, W, H, first=rank * nd)               # different frames on every rank
     frames_np = np.concatenate([distinct] * ((NF + nd - 1) // nd))[:NF]
     frames = torch.from_numpy(frames_np.view(np.int16)).to(dev)          # resident in HBM before timing
+    # a second, different batch (other subjects, other head positions): consecutive batches of a predictor alternate between
+    # the two, so that nothing that depends on the previous batch's content (k_boxsum does not rewrite zero over zero) sees the
+    # same frames twice in a row
+    other_np = np.roll(np.concatenate([synth.biwi_batch(nd, W, H, first=10000 + rank * nd)] * ((NF + nd - 1) // nd))[:NF], 7, axis=0)
+    frames_b = torch.from_numpy(other_np.view(np.int16)).to(dev)
+    batches = [frames, frames_b]
+    step_no = [0]
     hp = HoughPrediction(forest, model, device=local_rank)
     hp.reserve(NF, W, H)
     # pipeline depth: consecutive steps alternate between this many predictors (own workspace, own stream), so that the
@@ -124,7 +131,9 @@ def main():
         sp.capture(frames.data_ptr())
 
     def step():
-        sp.submit(frames.data_ptr(), stream)
+        i = step_no[0]
+        step_no[0] += 1
+        sp.submit((frames if args.graph else batches[(i // depth) % 2]).data_ptr(), stream)
 
     fence = sp.fence
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
@@ -143,6 +152,7 @@ def main():
         elapsed = float(t.item())
 
     gpu_poses = sp.last_poses() if rank == 0 else None     # gathered records of the last timed step (all ranks, rank order)
+    last_was_b = (not args.graph) and (((step_no[0] - 1) // depth) % 2 == 1)   # which of the two batches that step processed
     if args.dump_poses and rank == 0:
         np.save(args.dump_poses, gpu_poses)
     # run-to-run spread: the same K-step region twice more (untimed for `value`, which stays the first region)
@@ -165,8 +175,8 @@ def main():
     hp.set_profiling(True)
     acc = {"boxsum_ms": 0.0, "traverse_ms": 0.0, "emit_ms": 0.0, "vote_ms": 0.0, "cluster_ms": 0.0, "total_ms": 0.0}
     reps = max(3, min(10, args.steps))
-    for _ in range(reps):
-        hp.predict_batch_device(frames.data_ptr(), NF, W, H, intr, poses.data_ptr(), stream=stream.cuda_stream)
+    for r in range(reps):
+        hp.predict_batch_device(batches[r % 2].data_ptr(), NF, W, H, intr, poses.data_ptr(), stream=stream.cuda_stream)   # alternating, as in the timed region
         tm = hp.timing()
         for k in acc:
             acc[k] += tm[k] / reps
@@ -180,9 +190,9 @@ def main():
         rounds = 4
         for q in hps:
             q.set_profiling(True)
-        for _ in range(rounds):
+        for r in range(rounds):
             for k, q in enumerate(hps):
-                q.predict_batch_device(frames.data_ptr(), NF, W, H, intr, sp.pose_bufs[k % sp.slots].data_ptr(), stream=sp.streams[k].cuda_stream)
+                q.predict_batch_device(batches[r % 2].data_ptr(), NF, W, H, intr, sp.pose_bufs[k % sp.slots].data_ptr(), stream=sp.streams[k].cuda_stream)
             torch.cuda.synchronize(dev)
             for q in hps:
                 tm = q.timing()
@@ -282,7 +292,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32/f64",
-            "data": "synthetic",
+            "data": "synthetic (two different 256-frame batches per GPU, alternating)",
             "config": {"workload": f"BASELINE configs[1]: {NF} synthetic {W}x{H} u16 depth frames per GPU, "
                                    f"{args.trees}-tree depth-{args.depth} {args.forest} synthetic forest "
                                    f"({forest.n_nodes} nodes, {forest.n_leaves} leaves), stride-{args.stride} "
@@ -292,6 +302,7 @@ def main():
                        "batches_in_flight": depth},
             "roofline": roof,
             "repeat_ms_per_step": [round(r, 4) for r in repeats],
+            "last_step_batch": "b" if last_was_b else "a",      # which of the two alternating batches the last timed step processed (--dump-poses)
             "kernels_ms": kernels,
             "kernels_ms_in_flight": None if acc_fl is None else {k: round(v, 4) for k, v in acc_fl.items()},   # per launch, `batches_in_flight` at once
             # measured HBM traffic (PMC, gfx950-corrected) over the live duration of every kernel: shows which
@@ -309,6 +320,9 @@ def main():
             out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], ref_poses = cpu_baseline(forest, model, frames_np, K, args.cpu_seconds)
+            if last_was_b:
+                from oracle import pyoracle as po
+                ref_poses = po.predict_batch(forest, model, other_np, K, rect_mode=po.RECT_SAT, threads=host_cores())
             # the second half of BASELINE.json's metric ("pose L2 vs ref"): the GPU poses of the last timed step against
             # the oracle's for the very same frames (both are integer-grid values: the difference must be exactly 0)
             dm = np.linalg.norm(gpu_poses["mid_point"].astype(np.float64) - ref_poses["mid_point"].astype(np.float64), axis=1)

@@ -242,6 +242,7 @@ struct Knobs {
     int box_band = 64;                // DH_BOX_BAND
     int max_resident = 512;           // DH_MAX_RESIDENT_FRAMES
     int chunks = 0;                   // DH_CHUNKS: forked sub-batches per call; 0 = automatic (two once a call brings >= 512 frames)
+    bool box_dense = false;           // DH_BOX_DENSE: k_boxsum stores every cell (no skipping of zero over zero)
     bool no_region = false;           // DH_NO_REGION: k_cluster always gathers its first region itself
     int region_min_hits = 0;          // DH_REGION_MIN_HITS: hit records in a frame from which k_region pre-gathers its first regions (small batches);
                                       //   0 = automatic: 8192 for forests without leaf histogram (their rotation gather costs ~9 ns a record), 65536 with
@@ -266,6 +267,7 @@ static Knobs read_knobs() {
     k.box_band = std::max(1, geti("DH_BOX_BAND", 64));
     k.max_resident = std::max(1, geti("DH_MAX_RESIDENT_FRAMES", 512));
     k.chunks = std::max(0, std::min(8, geti("DH_CHUNKS", 0)));
+    k.box_dense = getenv("DH_BOX_DENSE") != nullptr;
     k.no_region = getenv("DH_NO_REGION") != nullptr;
     k.region_min_hits = std::max(0, geti("DH_REGION_MIN_HITS", 0));
     k.no_general_int = getenv("DH_NO_GENERAL_INT") != nullptr;
@@ -316,6 +318,7 @@ struct dh_predictor {
     HitBox *hit_box = nullptr;
     HitRot *hit_rot = nullptr;
     uint32_t *box = nullptr;         // [cap][box_rows][m][box_plane] rectangle-sum images (uniform path)
+    unsigned long long *box_mask = nullptr;   // [cap][ceil(box_rows / 32)][box_parts] which lanes wrote non-zero sums last time (BoxArgs::blk_mask)
     uint32_t *win_patch = nullptr;   // [cap][win_cap] window list: position in the window grid
     int32_t *win_leaf = nullptr;     // [cap][T][win_cap] window list: leaf per tree
     uint32_t *leaf_hits = nullptr;   // [cap][n_leaves] rotation-vote histogram (inside `counters`), only for forests of <= DH_LEAF_HIST_MAX leaves
@@ -417,11 +420,11 @@ static void drop_graph(dh_predictor *p) {
 static void free_workspace(dh_predictor *p) {
     // a captured batch has the old workspace pointers baked in: replaying it would touch freed memory
     if (p->graph_exec) { drop_graph(p); p->graph_stale = true; }
-    void *ptrs[] = {p->pre_region, p->box, p->win_patch, p->win_leaf, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
+    void *ptrs[] = {p->box_mask, p->pre_region, p->box, p->win_patch, p->win_leaf, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
                     p->dbg_flags, p->dbg_guess, p->dbg_trace, p->dbg_steps, p->dbg_votes, p->dbg_vcount};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    p->pre_region = nullptr; p->pre_cap = 0;
+    p->pre_region = nullptr; p->pre_cap = 0; p->box_mask = nullptr;
     p->box = nullptr; p->win_patch = nullptr; p->win_leaf = nullptr; p->leaf_hits = nullptr; p->zero_words = 0;
     p->aux_leaf = nullptr; p->aux_flags = nullptr; p->aux_u32 = nullptr; p->aux_out = nullptr; p->aux_out_bytes = 0; p->aux_cap = 0;
     p->ws_frames = nullptr; p->hits = nullptr; p->hit_box = nullptr; p->hit_rot = nullptr; p->counters = nullptr; p->ws_poses = nullptr; p->ws_midp = nullptr;
@@ -651,7 +654,8 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
         g.box_ow = std::min(ow_max, ((bw + g.box_parts - 1) / g.box_parts + 3) & ~3);
         const int band = p->knobs.box_band;
         g.box_bands = (g.box_rows + band - 1) / band;
-        g.box_oh = (g.box_rows + g.box_bands - 1) / g.box_bands;
+        g.box_oh = ((g.box_rows + g.box_bands - 1) / g.box_bands + 31) & ~31;     // whole 32-row blocks per band (BoxArgs::blk_mask)
+        g.box_bands = (g.box_rows + g.box_oh - 1) / g.box_oh;
     }
     return DH_OK;
 }
@@ -701,6 +705,12 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
         const size_t words = (size_t)cap * g.box_rows * ((size_t)g.box_plane << g.swz_log2);
         STEP(dev_alloc(p, &p->box, words));
         if (rc == DH_OK && hipMemset(p->box, 0, words * sizeof(uint32_t)) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box)");   // the slack columns stay 0
+        if (!p->knobs.box_dense) {
+            // zeroed together with the images: "cell non-zero => mask bit set" holds from the start
+            const size_t mw = (size_t)cap * ((g.box_rows + 31) / 32) * g.box_parts;
+            STEP(dev_alloc(p, &p->box_mask, mw));
+            if (rc == DH_OK && hipMemset(p->box_mask, 0, mw * sizeof(unsigned long long)) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box_mask)");
+        }
     }
     // one block, one memset per batch: hit counters | guess grids | tile flags | window counts | leaf histogram
     const size_t counter_words = (size_t)cap * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words + (size_t)g.tiles_x * g.tiles_y);
@@ -768,10 +778,12 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         if (ring_on && p->f_rh >= 2 && p->f_rh - 1 <= 28) {      // 4 x 28 x 512 B + the prefix rows < 64 KB
             const long waves_max = 12L * 256;
             int bands = (int)std::max(1L, std::min<long>(std::max(1, g.box_rows / 16), waves_max / std::max(1L, (long)n * g.box_parts)));
-            ba.oh = (g.box_rows + bands - 1) / bands;
+            ba.oh = ((g.box_rows + bands - 1) / bands + 31) & ~31;               // whole 32-row blocks per band (BoxArgs::blk_mask)
             ba.bands = (g.box_rows + ba.oh - 1) / ba.oh;
             ba.ring = 1;
         }
+        ba.mask_blocks = (g.box_rows + 31) / 32;
+        ba.blk_mask = p->box_mask ? p->box_mask + (size_t)f0 * ba.mask_blocks * g.box_parts : nullptr;
         ba.blocks_per_frame = (ba.parts * ba.bands + 3) / 4;
         HIP_TRY(dh_launch_boxsum(ba, s));
     }

@@ -161,6 +161,12 @@ struct BoxArgs {
     int parts, bands;       // waves across / down a frame
     int blocks_per_frame;   // ceil(parts * bands / 4)
     int ring;               // 1: keep the rh - 1 window rows in a wave-private LDS ring (rh - 1 <= 28) instead of re-reading them
+    // Sparse stores: [n_frames][ceil(rows / 32)][parts] 64-bit masks, bit l = lane l of that column part wrote a non-zero sum into
+    // that 32-row block the last time this frame slot was filled.  A lane whose four sums of a row are zero and whose bit is clear
+    // skips the store: the cells hold zero already (buffer and masks are zeroed together when the workspace is allocated, and every
+    // fill keeps "cell non-zero => bit set").  Band heights are multiples of 32 rows so that one wave owns a block.  NULL: store everything.
+    unsigned long long *blk_mask;
+    int mask_blocks;        // ceil(rows / 32)
 };
 
 // k_pixflags: tile flags of the general path (non-zero pixel under the tile's footprint).

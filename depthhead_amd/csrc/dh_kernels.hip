@@ -638,7 +638,7 @@ hipError_t dh_launch_pixflags(const PixFlagArgs &a, hipStream_t s) {
 // and every instance gets its own register budget.
 template <bool AL, bool RW4, int RIF, bool RING>
 __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const uint16_t *img, uint32_t *pex, uint2 *ring, uint32_t *out,
-                                            int lane, int x, int Y0, int y_end, bool store) {
+                                            int lane, int x, int Y0, int y_end, bool store, int part) {
     // Columns right of the image read a.zeros with row stride 0 instead of being masked, so every
     // load is unconditional and nothing has to wait for it before its use.
     const bool in0 = x < a.w, in1 = x + 1 < a.w, in2 = x + 2 < a.w, in3 = x + 3 < a.w;
@@ -669,6 +669,10 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
     const float r_tpx = 1.0f / (float)a.tpx, r_tpy = 1.0f / (float)a.tpy;
     uint2 e[RIF], l[RIF], en[RIF], ln[RIF];
     int rs = 0;                          // ring slot of step t: t mod (rh - 1)
+    // sparse stores (BoxArgs::blk_mask): the previous fill's non-zero mask of the 32-row block being emitted, and the next block's
+    unsigned long long *bm = a.blk_mask ? a.blk_mask + ((size_t)frame * a.mask_blocks) * a.parts + part : nullptr;
+    unsigned long long pblk = bm ? bm[(size_t)(Y0 >> 5) * a.parts] : ~0ull;
+    unsigned long long pnext = bm && ((Y0 >> 5) + 1) < a.mask_blocks ? bm[(size_t)((Y0 >> 5) + 1) * a.parts] : ~0ull;
 #pragma unroll
     for (int k = 0; k < RIF; ++k) {
         const int t = min(k, nsteps - 1);
@@ -703,8 +707,9 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
             uint4 r;
             if (RW4) r = *(const uint4 *)__builtin_assume_aligned(pex_rd, 16);
             else r = make_uint4(pex_rd[0], pex_rd[1], pex_rd[2], pex_rd[3]);
-            if (store) {
-                acc |= (r.x - pe.x) | (r.y - pe.y) | (r.z - pe.z) | (r.w - pe.w);
+            const uint32_t nzr = (r.x - pe.x) | (r.y - pe.y) | (r.z - pe.z) | (r.w - pe.w);
+            if (store) acc |= nzr;
+            if (store && (nzr != 0 || ((pblk >> lane) & 1ull))) {          // (zero over zero is not written again)
                 uint32_t *orow = out + (size_t)(Y0 + t - warm) * row_pitch;
                 if (a.lg == 0) *(uint4 *)(orow + o0) = make_uint4(r.x - pe.x, r.y - pe.y, r.z - pe.z, r.w - pe.w);
                 else if (a.lg == 1) {                      // two planes: columns x, x + 2 and x + 1, x + 3 are neighbours in theirs
@@ -718,6 +723,12 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
             // contain its columns and those rows (plain stores of 1: the flags are zeroed per batch).
             const int yo = Y0 + t - warm;
             if ((yo & 31) == 31 || yo == y_end - 1) {
+                if (bm) {
+                    const unsigned long long nm = __ballot(acc != 0);
+                    if (lane == 0) bm[(size_t)(yo >> 5) * a.parts] = nm;
+                    pblk = pnext;
+                    pnext = ((yo >> 5) + 2) < a.mask_blocks ? bm[(size_t)((yo >> 5) + 2) * a.parts] : ~0ull;
+                }
                 if (acc != 0) {
                     // tile tx covers columns [tx * tpx, tx * tpx + tbw): tx in [(x + 3 - tbw) / tpx + 1 .. x / tpx] clipped
                     const int y_lo = max(yo & ~31, Y0);
@@ -752,7 +763,7 @@ __global__ void __launch_bounds__(BOXW_THREADS) k_boxsum(BoxArgs a) {
     uint32_t *pex = pex_s[wv];
     uint2 *ring = (uint2 *)box_dyn + (size_t)wv * (a.rh - 1) * WAVE;
     uint32_t *out = a.out + (size_t)frame * a.rows * ((size_t)a.plane << a.lg);
-    boxsum_wave<AL, RW4, AL ? BOX_ROWS_IN_FLIGHT : 1, RING>(a, frame, img, pex, ring, out, lane, x, Y0, y_end, store);
+    boxsum_wave<AL, RW4, AL ? BOX_ROWS_IN_FLIGHT : 1, RING>(a, frame, img, pex, ring, out, lane, x, Y0, y_end, store, part);
 }
 
 hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s) {

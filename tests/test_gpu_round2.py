@@ -357,7 +357,10 @@ def test_two_rank_bench_rehearsal_on_one_gpu(oracle, hip_lib, tmp_path):
     model = synth.ModelParams(stepwidth=4)
     K = synth.default_intrinsic(w, h)
     for rank in range(2):
-        frames = synth.biwi_batch(nf, w, h, first=rank * nf)          # bench.py's frames of that rank
+        if out["last_step_batch"] == "a":
+            frames = synth.biwi_batch(nf, w, h, first=rank * nf)      # bench.py's first batch of that rank
+        else:
+            frames = np.roll(synth.biwi_batch(nf, w, h, first=10000 + rank * nf), 7, axis=0)   # ... its second, alternating batch
         ref = oracle.predict_batch(forest, model, frames, K)
         assert _poses_equal(got[rank * nf:(rank + 1) * nf], ref), f"rank {rank}"
 
