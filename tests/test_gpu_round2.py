@@ -553,3 +553,54 @@ def test_error_behaviour_of_the_round2_entry_points(hp_mod, hip_lib):
 
 
 import struct  # noqa: E402  (used by the test above)
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_box_image_stays_exact_across_batches(hp_mod, oracle, dense):
+    """k_boxsum skips stores of zero over zero, relying on what the same frame slot held after the previous batch.  One
+    predictor, a sequence of batches built to break that: content appears, moves, vanishes and reappears in the same
+    cells; batch sizes change (other band partition of the image, other frame slots); the sibling consumers run in
+    between.  Leaf indices (taps on from the start, so no reallocation resets the state) and poses against the oracle."""
+    forest = synth.fit_forest(6, 10, synth.FOREST_SEED_BASE + 91, n_frames=12, subset=1500)
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 640, 480
+    K = synth.default_intrinsic(w, h)
+    intr = hp_mod.IntrinsicMatrix(K)
+    rs = np.random.RandomState(17)
+    base = synth.biwi_batch(6, w, h, first=140)
+    zero = np.zeros((h, w), np.uint16)
+    dots = ((rs.rand(h, w) < 0.002) * rs.randint(1, 4000, (h, w))).astype(np.uint16)       # isolated pixels: thin non-zero stripes of sums
+    full = rs.randint(500, 3000, (h, w)).astype(np.uint16)
+    shifted = np.roll(base[0], (37, -91), axis=(0, 1))
+    half = base[1].copy(); half[:, :320] = 0
+    seq = [
+        np.stack([base[0], base[1], base[2]]),
+        np.stack([zero, base[1], zero]),                 # slots 0 and 2 lose their content
+        np.stack([base[0], zero, dots]),                 # slot 0 regains exactly what it had; slot 1 loses; slot 2 gets sparse pixels
+        np.stack([shifted]),                             # one frame: many short bands
+        np.stack([full, half, base[3], base[4], base[5], zero, dots, base[0], shifted]),   # nine frames: other band partition, new slots
+        np.stack([zero, zero, zero]),
+        np.stack([half, full, base[2]]),
+    ]
+    if dense:
+        os.environ["DH_BOX_DENSE"] = "1"
+    try:
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            hp.debug_enable(True)
+            hp.reserve(9, w, h)
+            for bi, frames in enumerate(seq):
+                n = frames.shape[0]
+                poses = hp.predict_batch(frames, intr)
+                leaf = hp.debug_leaf_indices(n, w, h)
+                flags = hp.debug_patch_flags(n, w, h)
+                for i in range(n):
+                    ref = oracle.predict(forest, model, frames[i], K)
+                    assert np.array_equal(flags[i], ref.patch_flags), (bi, i)
+                    assert np.array_equal(leaf[i], ref.leaf_idx), (bi, i)
+                    assert np.array_equal(poses["mid_point"][i], ref.mid_point) and np.array_equal(poses["rotation"][i], ref.rotation), (bi, i)
+                if bi in (1, 4):                          # the sibling consumers fill the same images
+                    m = hp.predict_mask(frames[:2])
+                    assert np.array_equal(m[1], oracle.predict_mask(forest, model, frames[1]))
+                    hp.debug_enable(True)
+    finally:
+        os.environ.pop("DH_BOX_DENSE", None)
