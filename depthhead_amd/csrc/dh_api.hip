@@ -246,6 +246,8 @@ struct Knobs {
     bool no_region = false;           // DH_NO_REGION: k_cluster always gathers its first region itself
     int region_min_hits = 0;          // DH_REGION_MIN_HITS: hit records in a frame from which k_region pre-gathers its first regions (small batches);
                                       //   0 = automatic: 8192 for forests without leaf histogram (their rotation gather costs ~9 ns a record), 65536 with
+    int top_levels = -1;              // DH_TOP_LEVELS: tree levels walked from the LDS copy of the tree tops (-1 = auto, 0 = none)
+    bool no_absorb = false;           // DH_NO_ABSORB: uniform path walks the guarded node table even when no node is ambiguous
     bool no_general_int = false;      // DH_NO_GENERAL_INT: general path with the f64 divisions on every visit
     int stage_chunk = 64;             // DH_STAGE_CHUNK: frames per upload chunk of the host entry points (copy of chunk k + 1 overlaps the kernels of chunk k)
     int host_threads = 8;             // DH_HOST_THREADS: host threads that validate / pack run-length coded payloads
@@ -271,6 +273,8 @@ static Knobs read_knobs() {
     k.no_region = getenv("DH_NO_REGION") != nullptr;
     k.region_min_hits = std::max(0, geti("DH_REGION_MIN_HITS", 0));
     k.no_general_int = getenv("DH_NO_GENERAL_INT") != nullptr;
+    k.no_absorb = getenv("DH_NO_ABSORB") != nullptr;
+    if (const char *e = getenv("DH_TOP_LEVELS")) k.top_levels = std::max(0, std::min(8, atoi(e)));
     k.stage_chunk = std::max(1, geti("DH_STAGE_CHUNK", 64));
     k.host_threads = std::max(1, std::min(64, geti("DH_HOST_THREADS", (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())))));
 #ifdef DH_PROFILING_KNOBS
@@ -294,6 +298,11 @@ struct dh_predictor {
     int f_rw = 0, f_rh = 0;
     void *nodes_g = nullptr;     // NodeG[n_nodes]: general-path nodes with integer split bounds (patches up to 255 x 255), else NULL
     void *nodes_u = nullptr;     // 16-byte compact nodes for the current region layout (uniform path)
+    void *nodes_a = nullptr;     // NodeU[n_nodes + 1]: the same nodes as the walk table of walk_absorb (children as byte offsets), or NULL
+    uint32_t *amb_flag = nullptr; // device word: 1 = some node of nodes_u has an ambiguity band (then nodes_a is not used)
+    bool absorb_ok = false;      // no node is ambiguous: the uniform path walks nodes_a
+    uint32_t *top_tab = nullptr; // [T][2^top_levels] {offsets, ilo} heap + [T][2^top_levels] entry offsets (k_top_build), copied to LDS by every tile
+    int top_levels = 0;
     long long nodes_u_key = 0;   // (ss_row, swizzle) the compact nodes were built for
     hipStream_t own_stream = nullptr;
     hipStream_t copy_stream = nullptr;    // host entry points: uploads run here, ahead of the kernels on own_stream
@@ -522,6 +531,11 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     STEP(dev_alloc(p, &p->kern_ord, DH_GRID3));
     STEP(dev_alloc(p, &p->zeros, 32));
     { uint4 *nu = nullptr; STEP(dev_alloc(p, &nu, p->n_nodes, true)); p->nodes_u = nu; }
+    if (p->n_nodes > 0 && (size_t)p->n_nodes + p->n_leaves < ((size_t)1 << 27) && !p->knobs.no_absorb) {   // (byte offsets into the table stay below 2^31)
+        uint4 *na = nullptr;
+        STEP(dev_alloc(p, &na, (size_t)p->n_nodes + 1, true)); p->nodes_a = na;
+        STEP(dev_alloc(p, &p->amb_flag, 1, true));
+    }
     if (rc == DH_OK && prm->subimage_width <= 255 && prm->subimage_height <= 255 && p->n_nodes > 0) {
         // Integer split bounds of the general path (NodeG, see k_traverse): with C_i = max(c_i, 1), delta = (s1 C2 - s2 C1) / (C1 C2)
         // and |d - delta| < 2^-35, so D = s1 C2 - s2 C1 <= floor((thr - 2^-34) C1 C2 - pad) decides Zero and
@@ -562,6 +576,29 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking), "hipStreamCreate");
     if (rc == DH_OK) hipstep(dh_launch_leaf_prepare(d, p->own_stream), "k_leaf_prepare launch");
     if (rc == DH_OK) hipstep(hipStreamSynchronize(p->own_stream), "k_leaf_prepare");
+    if (rc == DH_OK && p->nodes_a && p->f_uniform) {
+        // does any node carry an ambiguity band?  (independent of the region layout: probed once with a dummy one)
+        uint32_t any_amb = 1;
+        hipstep(hipMemsetAsync(p->amb_flag, 0, sizeof(uint32_t), p->own_stream), "hipMemset");
+        if (rc == DH_OK) hipstep(dh_launch_nodes_compact(d, 1, 0, 4, (uint32_t)(p->f_rw * p->f_rh), p->nodes_u, nullptr, p->amb_flag, p->own_stream), "k_nodes_compact launch");
+        if (rc == DH_OK) hipstep(hipMemcpyAsync(&any_amb, p->amb_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, p->own_stream), "hipMemcpy");
+        if (rc == DH_OK) hipstep(hipStreamSynchronize(p->own_stream), "k_nodes_compact");
+        p->absorb_ok = rc == DH_OK && any_amb == 0;
+        if (p->absorb_ok) {
+            // levels walked from LDS: as many as keep the copy (12 bytes per heap slot) within 4 KB per workgroup
+            int dt = 0;
+            while (dt < 6 && (size_t)p->n_trees * (2u << dt) * 12 <= 4096) ++dt;
+            if (p->knobs.top_levels >= 0) dt = p->knobs.top_levels;
+            while (dt > 0 && (size_t)p->n_trees * (1u << dt) * 12 > 48 * 1024) --dt;
+            p->top_levels = dt;
+            if (rc == DH_OK) {
+                uint32_t *tt = nullptr;
+                int r2 = dev_alloc(p, &tt, (size_t)p->n_trees * (1u << dt) * 3, true);
+                if (r2) rc = r2;
+                p->top_tab = tt;
+            }
+        }
+    }
     if (rc == DH_OK) rc = build_kernel_table(p);
     for (auto &e : p->ev)
         if (rc == DH_OK) hipstep(hipEventCreate(&e), "hipEventCreate");
@@ -612,6 +649,7 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
     if (p->knobs.lds_budget_kb > 0) budget = (size_t)p->knobs.lds_budget_kb * 1024;
     budget = std::min<size_t>(budget, 158 * 1024);
     const int fx = p->knobs.tile_x, fy = p->knobs.tile_y;
+    const int top_words = g.uniform && p->absorb_ok ? (int)p->n_trees * (1 << p->top_levels) * 3 : 0;
     long best = -1;
     for (int py = 1; py <= std::min(g.ny, 64); ++py)
         for (int px = 1; px <= std::min(g.nx, 64); ++px) {
@@ -621,7 +659,7 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
             if (rw > 0 && (px & 3) != 0 && px < g.nx && !(fx > 0)) continue;
             // uniform path: the packed rectangle offsets of a compact node are 14-bit
             if (rw > 0 && (long)(sh - rh + 1) * dh_traverse_row_stride(px, step, sw, rw) >= 16384) continue;
-            size_t lds = dh_traverse_lds_bytes(px, py, step, sw, sh, (int)p->n_trees, rw, rh);
+            size_t lds = dh_traverse_lds_bytes(px, py, step, sw, sh, top_words, rw, rh);
             if (lds > budget && !(fx > 0 && lds <= 158 * 1024)) continue;
             long score = (long)px * py * 1000 - labs((long)px - py);
             if (score > best) { best = score; g.px = px; g.py = py; g.lds = lds; }
@@ -630,7 +668,7 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
         // a single position must always fit
         if (rw > 0 && (long)(sh - rh + 1) * dh_traverse_row_stride(1, step, sw, rw) >= 16384) return 1;   // caller retries on the general path
         g.px = g.py = 1;
-        g.lds = dh_traverse_lds_bytes(1, 1, step, sw, sh, (int)p->n_trees, rw, rh);
+        g.lds = dh_traverse_lds_bytes(1, 1, step, sw, sh, top_words, rw, rh);
         if (g.lds > 158 * 1024) return rw > 0 ? 1 : fail(DH_ESIZE, "patch %dx%d with %u trees does not fit LDS", sw, sh, p->n_trees);
     }
     g.tiles_x = (g.nx + g.px - 1) / g.px;
@@ -733,7 +771,9 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     if (rc != DH_OK) { free_workspace(p); return rc; }
     const long long nkey = ((long long)g.ss_row << 32) | ((long long)g.swz_q << 4) | g.swz_log2;
     if (g.npatch > 0 && g.uniform && p->nodes_u_key != nkey) {     // compact nodes carry LDS offsets for this row stride
-        hipError_t e = dh_launch_nodes_compact(p->dev, g.ss_row, g.swz_log2, g.swz_q, (uint32_t)(p->f_rw * p->f_rh), p->nodes_u, p->own_stream);
+        hipError_t e = dh_launch_nodes_compact(p->dev, g.ss_row, g.swz_log2, g.swz_q, (uint32_t)(p->f_rw * p->f_rh), p->nodes_u,
+                                               p->absorb_ok ? p->nodes_a : nullptr, nullptr, p->own_stream);
+        if (e == hipSuccess && p->absorb_ok) e = dh_launch_top_build(p->dev, p->nodes_a, p->top_levels, p->top_tab, p->own_stream);
         if (e == hipSuccess) e = hipStreamSynchronize(p->own_stream);
         if (e != hipSuccess) { free_workspace(p); return fail(DH_EHIP, "k_nodes_compact: %s", hipGetErrorString(e)); }
         p->nodes_u_key = nkey;
@@ -804,7 +844,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.nx = g.nx; ta.ny = g.ny; ta.px = g.px; ta.py = g.py; ta.tiles_x = g.tiles_x; ta.tiles_y = g.tiles_y;
         ta.ss_max = g.ss_max; ta.ss_row = g.ss_row; ta.swz_log2 = g.swz_log2; ta.swz_q = g.swz_q;
         ta.uniform = g.uniform ? 1 : 0; ta.rw = p->f_rw; ta.rh = p->f_rh; ta.area = (uint32_t)(p->f_rw * p->f_rh);
-        ta.nodes_u = p->nodes_u; ta.nodes_g = p->knobs.no_general_int ? nullptr : p->nodes_g;
+        ta.nodes_u = p->nodes_u; ta.nodes_a = p->absorb_ok ? p->nodes_a : nullptr; ta.top_tab = p->top_tab; ta.top_levels = p->top_levels; ta.nodes_g = p->knobs.no_general_int ? nullptr : p->nodes_g;
         ta.box = box; ta.box_plane = g.box_plane; ta.box_rows = g.box_rows;
         ta.tile_flags = tile_flags;
 #ifdef DH_PROFILING_KNOBS
@@ -1610,7 +1650,8 @@ extern "C" int dh_debug_geometry(dh_predictor *p, int32_t out[10]) {
     if (!p || !out) return fail(DH_EINVAL, "NULL argument");
     if (p->cap_frames == 0) return fail(DH_ESTATE, "no workspace yet (dh_predictor_reserve or a batch)");
     const Geom &g = p->geom;
-    const int32_t v[10] = {g.uniform ? 1 : 0, g.px, g.py, g.tiles_x, g.tiles_y, g.swz_log2, g.swz_q, g.ss_row, p->f_rw, p->f_rh};
+    const bool walk_tab = g.uniform && p->absorb_ok;
+    const int32_t v[10] = {(g.uniform ? 1 : 0) | (walk_tab ? 1 << 8 : 0) | (walk_tab ? p->top_levels << 16 : 0), g.px, g.py, g.tiles_x, g.tiles_y, g.swz_log2, g.swz_q, g.ss_row, p->f_rw, p->f_rh};
     memcpy(out, v, sizeof v);
     return DH_OK;
 }

@@ -219,9 +219,18 @@ struct __attribute__((aligned(16))) NodeU {
     int32_t  child_one;
 };
 
-__global__ void __launch_bounds__(256) k_nodes_compact(const dh_node *nodes, uint32_t n, int ss, int swz_log2, int swz_q, uint32_t area, NodeU *out) {
+__global__ void __launch_bounds__(256) k_nodes_compact(const dh_node *nodes, uint32_t n, int ss, int swz_log2, int swz_q, uint32_t area, NodeU *out,
+                                                       NodeU *out_a, uint32_t *any_amb) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n) {
+        // walk table (see walk_absorb): entry n is the one every finished walk re-reads (both box-sum offsets 0, never greater)
+        if (out_a && i == n) {
+            NodeU o;
+            o.offs = 0; o.ilo = INT32_MAX; o.child_zero = o.child_one = (int32_t)(i << 4);
+            out_a[i] = o;
+        }
+        return;
+    }
     dh_node nd = nodes[i];
     const double c = (double)area, thr = nd.threshold;
     int32_t ilo;
@@ -248,11 +257,58 @@ __global__ void __launch_bounds__(256) k_nodes_compact(const dh_node *nodes, uin
     o.child_zero = nd.child_zero;
     o.child_one = nd.child_one;
     out[i] = o;
+    if (amb && any_amb) atomicOr(any_amb, 1u);
+    if (out_a) {
+        // walk table: BYTE offsets (two half words) of the two box sums; children as byte offsets into this table, leaf l as the
+        // (virtual) offset of entry n + l -- anything from entry n on means "finished"
+        o.offs = (o1 << 2) | (o2 << 18);
+        o.child_zero = (int32_t)((nd.child_zero >= 0 ? (uint32_t)nd.child_zero : n + (uint32_t)~nd.child_zero) << 4);
+        o.child_one = (int32_t)((nd.child_one >= 0 ? (uint32_t)nd.child_one : n + (uint32_t)~nd.child_one) << 4);
+        out_a[i] = o;
+    }
 }
 
-hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int swz_q, uint32_t area, void *out, hipStream_t s) {
+hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int swz_q, uint32_t area, void *out, void *out_a, uint32_t *any_amb, hipStream_t s) {
     if (f.n_nodes == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_nodes_compact, dim3((f.n_nodes + 255) / 256), dim3(256), 0, s, f.nodes, f.n_nodes, ss, swz_log2, swz_q, area, (NodeU *)out);
+    const uint32_t n = f.n_nodes + (out_a ? 1 : 0);
+    hipLaunchKernelGGL(k_nodes_compact, dim3((n + 255) / 256), dim3(256), 0, s, f.nodes, f.n_nodes, ss, swz_log2, swz_q, area, (NodeU *)out,
+                       (NodeU *)out_a, any_amb);
+    return hipGetLastError();
+}
+
+// Tree tops for walk_absorb: the first DT levels of tree t as an implicit binary heap (slot h has its Zero child at 2h + 1 and
+// its One child at 2h + 2), each slot = {box-sum byte offsets, ilo} of the node there -- or an absorbing {0, INT32_MAX} when the
+// path to the slot has already ended in a leaf -- followed by the walk-table entry (byte offset into nodes_a) a walk stands at after
+// those DT levels.  Layout: [T][2^DT] uint2 heap (the last slot of a tree unused), then [T][2^DT] uint32 entries.
+__global__ void __launch_bounds__(64) k_top_build(const NodeU *tab, const int32_t *roots, uint32_t n_nodes, uint32_t T, int DT, uint32_t *out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t hs = 1u << DT, lb = n_nodes << 4;
+    uint2 *heap = (uint2 *)out + (size_t)t * hs;
+    uint32_t *entry = out + (size_t)T * hs * 2 + (size_t)t * hs;
+    const int32_t r = roots[t];
+    const uint32_t root = r >= 0 ? (uint32_t)r << 4 : lb + ((uint32_t)~r << 4);
+    for (uint32_t h = 0; h < 2 * hs - 1; ++h) {
+        // the bits of h + 1 below its leading one spell the path from the root: 0 = Zero child, 1 = One child
+        uint32_t cur = root;
+        const int len = 31 - __clz((int)(h + 1));
+        for (int b = len - 1; b >= 0 && cur < lb; --b) {
+            const NodeU nd = tab[cur >> 4];
+            cur = (uint32_t)((((h + 1) >> b) & 1u) ? nd.child_one : nd.child_zero);
+        }
+        if (h < hs - 1) {
+            const NodeU nd = tab[min(cur, lb) >> 4];          // (entry n reads {0, INT32_MAX}: the path has ended)
+            heap[h] = make_uint2(nd.offs, (uint32_t)nd.ilo);
+        } else {
+            entry[h - (hs - 1)] = cur;
+        }
+    }
+    heap[hs - 1] = make_uint2(0u, (uint32_t)INT32_MAX);
+}
+
+hipError_t dh_launch_top_build(const DevForest &f, const void *nodes_a, int top_levels, uint32_t *out, hipStream_t s) {
+    if (f.n_trees == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_top_build, dim3((f.n_trees + 63) / 64), dim3(64), 0, s, (const NodeU *)nodes_a, f.roots, f.n_nodes, f.n_trees, top_levels, out);
     return hipGetLastError();
 }
 
@@ -307,13 +363,12 @@ int dh_traverse_row_stride(int px, int step, int sw, int rw) {
     if (rw > 0) { int lg, q, ss; dh_traverse_swizzle(px, step, sw, rw, &lg, &q, &ss); return ss; }
     return ((px - 1) * step + sw + 1) | 1;
 }
-size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int n_trees, int rw, int rh) {
+size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int top_words, int rw, int rh) {
     size_t fh = (size_t)(py - 1) * step + sh;
     size_t ss = (size_t)dh_traverse_row_stride(px, step, sw, rw);
     size_t rows = rw > 0 ? fh - rh + 1 : fh + 1;
     size_t npt = (size_t)px * py;
-    (void)n_trees;
-    return (ss * rows + npt * 2 + 16) * 4;   // keep in step with the carve-up in k_traverse
+    return (ss * rows + npt * 2 + 16 + (size_t)top_words) * 4;   // keep in step with the carve-up in k_traverse
 }
 
 // n / d for 0 <= n < 2^22 and d >= 1, given rd = 1.0f / d: the float estimate is off by at most one
@@ -848,6 +903,93 @@ __device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32
     }
 }
 
+// The same walks over the walk table nodes_a (k_nodes_compact's second output; used when no node of the forest has an
+// ambiguity band, which the host checks at predictor creation).  What bounds a level of these walks is the 16-byte node gather
+// (vector-memory path and its latency), not the arithmetic -- cutting the loop from 42 to 17 VALU instructions alone changed
+// nothing (profiles/r02_traverse_experiments.md) -- so:
+//  * the first top_levels levels of every tree are walked from an LDS copy (k_top_build: implicit heap, 8-byte slots, no child
+//    pointers), which takes a third of the gathers off that path;
+//  * children are byte offsets into the table (the load needs no address arithmetic), leaf l is the virtual offset of entry
+//    n_nodes + l, and a finished walk re-reads entry n_nodes, the same line for every finished lane: a gather costs by the distinct
+//    lines its lanes touch;
+//  * the loop is wave-uniform (no per-walk exec masks): two half-word byte offsets -> two LDS reads, subtract, compare, select.
+template <int W>
+__device__ __forceinline__ void walk_absorb(const TraverseArgs &a, const uint32_t *sat, const uint32_t *top, int32_t *wleaf, int32_t *dleaf,
+                                            const uint32_t *active, const uint32_t *agp, int n_active, int total, int cx, int ss, int T) {
+    const int tid = threadIdx.x;
+    const char *tab = (const char *)a.nodes_a;
+    const uint32_t lb = a.f.n_nodes << 4;            // byte offset of the first absorbing entry
+    const int DT = a.top_levels;
+    const uint32_t hs = 1u << DT;
+    const char *entries = (const char *)(top + (size_t)T * hs * 2);
+    const float r_active = 1.0f / (float)n_active, r_cx = 1.0f / (float)cx;
+    for (int k0 = tid; k0 < total; k0 += W * TRAV_THREADS) {
+        uint32_t cur[W];
+        int dst[W], ddst[W];
+        const char *sp[W];
+        uint32_t hb[W], h[W];      // byte offset of the tree's heap in the LDS copy of the tree tops; slot in it
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const int k = k0 + i * TRAV_THREADS;
+            const int kk = k < total ? k : k0;
+            const int t = div_small(kk, n_active, r_active), slot = kk - t * n_active;
+            const int p = (int)active[slot];
+            const int py = div_small(p, cx, r_cx), px = p - py * cx;
+            sp[i] = (const char *)(sat + py * a.step * ss + ((px * a.step) >> a.swz_log2));   // window origins are multiples of m
+            dst[i] = t * a.win_cap + slot;
+            ddst[i] = dleaf ? (int)agp[slot] * T + t : 0;
+            hb[i] = ((uint32_t)t * hs) << 3;
+            h[i] = 0;
+        }
+        // the tree tops: levels 0 .. DT-1 from LDS (children are implicit; a path that has ended sits on absorbing slots)
+        for (int l = 0; l < DT; ++l) {
+            uint2 nd[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) nd[i] = *(const uint2 *)((const char *)top + hb[i] + (h[i] << 3));
+            uint32_t s1[W], s2[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                s1[i] = *(const uint32_t *)(sp[i] + (nd[i].x & 0xffffu));
+                s2[i] = *(const uint32_t *)(sp[i] + (nd[i].x >> 16));
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i) h[i] = 2 * h[i] + (((int32_t)s1[i] - (int32_t)s2[i] > (int32_t)nd[i].y) ? 2u : 1u);
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const uint32_t e = *(const uint32_t *)(entries + (hb[i] >> 1) + ((h[i] - (hs - 1)) << 2));
+            cur[i] = k0 + i * TRAV_THREADS < total ? e : lb;
+        }
+        for (;;) {
+            uint32_t mn = cur[0];
+#pragma unroll
+            for (int i = 1; i < W; ++i) mn = min(mn, cur[i]);
+            if (__ballot(mn < lb) == 0ull) break;
+            uint4 n[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) n[i] = *(const uint4 *)(tab + min(cur[i], lb));   // finished walks all re-read ONE entry: a gather costs by its distinct lines
+            uint32_t s1[W], s2[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                s1[i] = *(const uint32_t *)(sp[i] + (n[i].x & 0xffffu));
+                s2[i] = *(const uint32_t *)(sp[i] + (n[i].x >> 16));
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const uint32_t nx = ((int32_t)s1[i] - (int32_t)s2[i] > (int32_t)n[i].y) ? n[i].w : n[i].z;
+                cur[i] = cur[i] >= lb ? cur[i] : nx;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            if (k0 + i * TRAV_THREADS < total) {
+                const int32_t leaf = (int32_t)((cur[i] - lb) >> 4);
+                wleaf[dst[i]] = leaf;
+                if (dleaf) dleaf[ddst[i]] = leaf;
+            }
+    }
+}
+
 // GI (general path, patches of at most 255 x 255): split tests decided on integers.  With C_i = max(c_i, 1) (an empty
 // rectangle sums to 0, types.rs:335-338) the real difference of the two means is delta = (s1 C2 - s2 C1) / (C1 C2), and the
 // reference's d = fl(fl(s1 / c1) - fl(s2 / c2)) satisfies |d - delta| < 2^-35 as on the uniform path, so
@@ -962,6 +1104,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     uint32_t *active = sat + a.ss_max;         // [px * py] window (inside the tile) of every active slot
     uint32_t *agp = active + a.px * a.py;      // [px * py] its position in the frame's window grid
     uint32_t *misc = agp + a.px * a.py;        // [0] n_active, [4] any pixel
+    uint32_t *top = misc + 16;                 // (UNI && GI) the tree tops of walk_absorb
 
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
 #ifdef DH_PROFILING_KNOBS
@@ -1012,6 +1155,10 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
                 yy += qd; xx += rd;
                 if (xx >= bw) { xx -= bw; ++yy; }
             }
+        }
+        if (GI) {
+            const int tw = T * (1 << a.top_levels) * 3;
+            for (int i = tid; i < tw; i += TRAV_THREADS) top[i] = a.top_tab[i];
         }
         __syncthreads();
     }
@@ -1114,6 +1261,12 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         // independent, so each lane keeps W dependent-load chains in flight.  W = walks per lane
         // of this tile (at most 4), so one pass covers the tile whenever it has <= 4096 walks.
         const int per_lane = (total + TRAV_THREADS - 1) / TRAV_THREADS;
+        if (GI) {                   // (uniform path: the second template flag selects the absorbing-leaf walk table)
+            if (per_lane <= 1) walk_absorb<1>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+            else if (per_lane == 2) walk_absorb<2>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+            else if (per_lane == 3) walk_absorb<3>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+            else walk_absorb<4>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+        } else
         if (per_lane <= 1) walk_uniform<1>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
         else if (per_lane == 2) walk_uniform<2>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
         else if (per_lane == 3) walk_uniform<3>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
@@ -1356,6 +1509,7 @@ hipError_t dh_kernels_init() {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_traverse<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -1369,7 +1523,8 @@ hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream
     if (tiles == 0 || fb == 0) return hipSuccess;
     if (tiles > 65535 || fb > 65535) return hipErrorInvalidConfiguration;
     const dim3 grid(8, tiles, fb);
-    if (a.uniform) hipLaunchKernelGGL((k_traverse<true, false>), grid, dim3(TRAV_THREADS), lds_bytes, s, a);
+    if (a.uniform && a.nodes_a) hipLaunchKernelGGL((k_traverse<true, true>), grid, dim3(TRAV_THREADS), lds_bytes, s, a);
+    else if (a.uniform) hipLaunchKernelGGL((k_traverse<true, false>), grid, dim3(TRAV_THREADS), lds_bytes, s, a);
     else if (a.nodes_g) hipLaunchKernelGGL((k_traverse<false, true>), grid, dim3(TRAV_THREADS), lds_bytes, s, a);
     else hipLaunchKernelGGL((k_traverse<false, false>), grid, dim3(TRAV_THREADS), lds_bytes, s, a);
     return hipGetLastError();

@@ -297,7 +297,10 @@ class HoughPrediction:
         out = np.zeros(10, dtype=np.int32)
         check(self._lib.dh_debug_geometry(self._ph, vp(out)))
         keys = ("uniform", "px", "py", "tiles_x", "tiles_y", "swz_log2", "swz_q", "ss_row", "rw", "rh")
-        return dict(zip(keys, (int(x) for x in out)))
+        geo = dict(zip(keys, (int(x) for x in out)))
+        path = geo["uniform"]
+        geo.update(uniform=path & 1, walk_table=(path >> 8) & 1, top_levels=path >> 16)
+        return geo
 
     def debug_hit_counts(self, n: int) -> np.ndarray:
         out = np.zeros(n, dtype=np.uint32)

@@ -604,3 +604,63 @@ def test_box_image_stays_exact_across_batches(hp_mod, oracle, dense):
                     hp.debug_enable(True)
     finally:
         os.environ.pop("DH_BOX_DENSE", None)
+
+
+def _stunted_forest(seed):
+    """A forest whose trees end at every depth from 0 (a root that is a leaf) on, so that paths end inside the levels the
+    uniform path walks from its LDS copy of the tree tops."""
+    from depthhead_amd.forest import NODE_DTYPE, Forest
+    base = synth.synth_forest(6, 7, seed)
+    rs = np.random.RandomState(seed)
+    nodes = base.nodes.copy()
+    roots = base.roots.copy()
+    # cut sub-trees short: point some children straight at a leaf
+    for i in rs.choice(len(nodes), size=len(nodes) // 5, replace=False):
+        nodes["child_one" if rs.rand() < 0.5 else "child_zero"][i] = ~int(rs.randint(0, len(base.leaf_prob)))
+    roots[1] = ~int(rs.randint(0, len(base.leaf_prob)))                 # a tree that is one leaf
+    roots[4] = int(nodes["child_zero"][roots[4]]) if nodes["child_zero"][roots[4]] >= 0 else roots[4]
+    return Forest(roots, nodes, base.leaf_prob, base.off_begin, base.rot_begin, base.offsets, base.rotations)
+
+
+@pytest.mark.parametrize("knob", [None, "DH_NO_ABSORB=1", "DH_TOP_LEVELS=0", "DH_TOP_LEVELS=1", "DH_TOP_LEVELS=3", "DH_TOP_LEVELS=8"])
+def test_walk_table_variants(hp_mod, oracle, knob):
+    """The uniform path's walks: the guarded node table (DH_NO_ABSORB) and the unguarded walk table with 0..8 tree levels taken
+    from LDS, on a forest with paths ending at every depth (also a tree that is a single leaf): same leaves, votes and poses."""
+    from test_gpu_parity import _check_frames
+    forest = _stunted_forest(77)
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 200, 168
+    frames = synth.biwi_batch(3, w, h, first=33)
+    env = dict([knob.split("=")]) if knob else {}
+    os.environ.update(env)
+    try:
+        _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), full=True)
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            hp.reserve(3, w, h)
+            geo = hp.debug_geometry()
+            assert geo["uniform"] == 1
+            assert geo["walk_table"] == (0 if knob == "DH_NO_ABSORB=1" else 1)
+            if knob and knob.startswith("DH_TOP_LEVELS"):
+                assert geo["top_levels"] == int(env["DH_TOP_LEVELS"])
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+def test_ambiguous_threshold_keeps_the_guarded_walks(hp_mod, oracle):
+    """One node whose threshold times the rectangle area is an integer has an ambiguity band (k_nodes_compact): the predictor
+    then keeps the guarded node table, whose walks resolve the band with the reference's f64 arithmetic."""
+    from test_gpu_parity import _check_frames
+    forest = synth.synth_forest(4, 6, 91)
+    nodes = forest.nodes.copy()
+    nodes["threshold"][int(forest.roots[0])] = 3.0
+    from depthhead_amd.forest import Forest
+    forest = Forest(forest.roots, nodes, forest.leaf_prob, forest.off_begin, forest.rot_begin, forest.offsets, forest.rotations)
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 160, 120
+    frames = synth.biwi_batch(2, w, h, first=5)
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), full=True)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.reserve(2, w, h)
+        geo = hp.debug_geometry()
+        assert geo["uniform"] == 1 and geo["walk_table"] == 0
