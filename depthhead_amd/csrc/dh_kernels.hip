@@ -1260,7 +1260,11 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         // W walks per lane, advanced in lock step: their node fetches and box-sum reads are
         // independent, so each lane keeps W dependent-load chains in flight.  W = walks per lane
         // of this tile (at most 4), so one pass covers the tile whenever it has <= 4096 walks.
-        const int per_lane = (total + TRAV_THREADS - 1) / TRAV_THREADS;
+        // (per WAVE: the last pass over the items is usually filled in part, and a wave without items in it walks one chain
+        // fewer -- every lock-step level of a chain is a node gather of the whole wave, whatever its lanes hold)
+        const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~(WAVE - 1));
+        const int all_passes = (total - wave_first + TRAV_THREADS - 1) / TRAV_THREADS;
+        const int per_lane = all_passes > 4 ? (total + TRAV_THREADS - 1) / TRAV_THREADS : all_passes;
         if (GI) {                   // (uniform path: the second template flag selects the absorbing-leaf walk table)
             if (per_lane <= 1) walk_absorb<1>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
             else if (per_lane == 2) walk_absorb<2>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
