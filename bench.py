@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (other configs, PCIe-inclusive rates): profiling runs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
-    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight per GPU (predictors / streams that consecutive steps alternate between)")
+    ap.add_argument("--pipeline", type=int, default=4, help="batches in flight per GPU (predictors / streams that consecutive steps alternate between)")
     ap.add_argument("--dump-poses", default=None, help="rank 0 writes the gathered pose records of the last timed step (all ranks, rank order) as .npy")
     return ap.parse_args()
 
@@ -263,7 +263,7 @@ def main():
                 "launch_ms_is": "the kernel's duration with ONE batch in flight (HIP events around every kernel of a dedicated pass, "
                                 "as in profiles/*_kernel_stats.csv = rocprofv3 --stats of `bench.py --pipeline 1`); in the timed region "
                                 f"{depth} batches are in flight and kernels of consecutive batches share the chip "
-                                "(profiles/*_kernel_stats_2inflight.csv)",
+                                "(profiles/*_kernel_stats_inflight.csv)",
                 # the same algorithmic bytes over the whole step (all five kernels): what the job as a whole reaches
                 "whole_step_frac": round(b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
                 "note": "achieved = algorithmic bytes of the launch / duration of the dominant kernel (live HIP events). "

@@ -247,6 +247,7 @@ struct Knobs {
     int region_min_hits = 0;          // DH_REGION_MIN_HITS: hit records in a frame from which k_region pre-gathers its first regions (small batches);
                                       //   0 = automatic: 8192 for forests without leaf histogram (their rotation gather costs ~9 ns a record), 65536 with
     int top_levels = -1;              // DH_TOP_LEVELS: tree levels walked from the LDS copy of the tree tops (-1 = auto, 0 = none)
+    bool vote_exact = false;          // DH_VOTE_EXACT: k_vote takes the two IEEE divisions for every vote (no approximate-quotient cell test)
     bool no_absorb = false;           // DH_NO_ABSORB: uniform path walks the guarded node table even when no node is ambiguous
     bool no_general_int = false;      // DH_NO_GENERAL_INT: general path with the f64 divisions on every visit
     int stage_chunk = 64;             // DH_STAGE_CHUNK: frames per upload chunk of the host entry points (copy of chunk k + 1 overlaps the kernels of chunk k)
@@ -274,6 +275,7 @@ static Knobs read_knobs() {
     k.region_min_hits = std::max(0, geti("DH_REGION_MIN_HITS", 0));
     k.no_general_int = getenv("DH_NO_GENERAL_INT") != nullptr;
     k.no_absorb = getenv("DH_NO_ABSORB") != nullptr;
+    k.vote_exact = getenv("DH_VOTE_EXACT") != nullptr;
     if (const char *e = getenv("DH_TOP_LEVELS")) k.top_levels = std::max(0, std::min(8, atoi(e)));
     k.stage_chunk = std::max(1, geti("DH_STAGE_CHUNK", 64));
     k.host_threads = std::max(1, std::min(64, geti("DH_HOST_THREADS", (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())))));
@@ -892,7 +894,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     if (traverse_only) return DH_OK;
     {
         VoteArgs va{};
-        va.n_frames = n; va.w = w; va.h = h;
+        va.n_frames = n; va.w = w; va.h = h; va.cell_fast = p->knobs.vote_exact ? 0 : 1;
         memcpy(va.k, K, sizeof va.k);
         va.f = p->dev; va.hits = p->hits + hoff; va.hit_box = p->hit_box + hoff; va.hit_rot = p->hit_rot + hoff;
         va.hit_count = hit_count; va.hits_cap = p->hits_cap;

@@ -194,6 +194,8 @@ struct VoteArgs {
     uint32_t *rot_grid;     // [n][8000]
     const uint32_t *leaf_hits; // nullable [n][n_leaves]: rotation votes per leaf (k_emit); then the 20^3 grid is built per leaf, not per hit
     int stop;               // profiling knob (env DH_VOTE_STOP): 1 / 2 / 3 = return after the LDS set-up / the hit records / the leaf histogram
+    int cell_fast;          // w and h are multiples of 20: a vote's guess-grid cell may be taken from an approximate quotient (vote_positions)
+    float sx, sy;           // 20 / w, 20 / h
 };
 
 struct ClusterArgs {

@@ -1578,14 +1578,30 @@ __device__ __forceinline__ void vote_positions(const VoteArgs &a, uint32_t *pos,
             } else {
                 matvec3(a.k, nx, ny, nz, r);                                      // types.rs:425
             }
-            float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
-            float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;           // :662
-            float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;           // :663
-            // x2 in [0, w-1] and never NaN after the clamps: `as usize` is a plain truncation
-            const uint32_t xi = (uint32_t)x2, yi = (uint32_t)y2;
-            const uint32_t gx = TAB ? gxt[xi] : xi * DH_GRID / (uint32_t)a.w;      // :671-672
-            const uint32_t gy = TAB ? gyt[yi] : yi * DH_GRID / (uint32_t)a.h;
-            const uint32_t idx = gy * DH_GRID + gx;
+            // Only the CELL of the 20 x 20 grid is needed here.  When w and h are multiples of 20 (cells are whole pixels wide)
+            // the cell of the reference's clamped, truncated quotient x2 (:662-672) is floor(clamp(x2 * 20 / w)), and an
+            // approximate quotient decides it whenever it is not next to a cell border: with v_rcp_f32 (1 ulp) and three more
+            // roundings u~ = (r0 * rcp(r2)) * (20 / w) is within 2.5 * 2^-23 * |u| < 7e-6 of the real u for |u| <= 21, the
+            // reference's own rounding of r0 / r2 moves it by < 2e-6 more, and outside [0, 20) both sides clamp into cell 0 / 19
+            // wherever they are.  Quotients within 1e-4 of an integer, and everything not finite (r2 = 0, NaN), take the two
+            // IEEE divisions -- 0.04 % of the votes.  Saves 22 of the 52 VALU instructions of a vote.
+            uint32_t idx;
+            const float rc = __builtin_amdgcn_rcpf(r[2]);
+            const float ux = __fmul_rn(__fmul_rn(r[0], rc), a.sx), uy = __fmul_rn(__fmul_rn(r[1], rc), a.sy);
+            const bool near_border = !(fabsf(__fsub_rn(ux, rintf(ux))) > 1.0e-4f) || !(fabsf(__fsub_rn(uy, rintf(uy))) > 1.0e-4f);
+            if (a.cell_fast && !near_border) {
+                const float cxf = fminf(fmaxf(ux, 0.0f), 19.5f), cyf = fminf(fmaxf(uy, 0.0f), 19.5f);
+                idx = (uint32_t)cyf * DH_GRID + (uint32_t)cxf;
+            } else {
+                float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
+                float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;           // :662
+                float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;           // :663
+                // x2 in [0, w-1] and never NaN after the clamps: `as usize` is a plain truncation
+                const uint32_t xi = (uint32_t)x2, yi = (uint32_t)y2;
+                const uint32_t gx = TAB ? gxt[xi] : xi * DH_GRID / (uint32_t)a.w;      // :671-672
+                const uint32_t gy = TAB ? gyt[yi] : yi * DH_GRID / (uint32_t)a.h;
+                idx = gy * DH_GRID + gx;
+            }
             if (idx != last) {
                 if (acc) atomicAdd(&pos[last], acc);                              // :675
                 last = idx; acc = 0;
@@ -1678,12 +1694,15 @@ hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
     if (a.n_frames == 0) return hipSuccess;
     const bool pin = a.k[1] == 0.0f && a.k[3] == 0.0f && a.k[6] == 0.0f && a.k[7] == 0.0f && a.k[8] == 1.0f;
     const dim3 grid(VOTE_SLICES, a.n_frames), block(VOTE_THREADS);
+    VoteArgs b = a;
+    b.cell_fast = a.cell_fast && a.w % DH_GRID == 0 && a.h % DH_GRID == 0 && a.w > 0 && a.h > 0;
+    b.sx = (float)DH_GRID / (float)a.w; b.sy = (float)DH_GRID / (float)a.h;
     if (a.w <= VOTE_TAB && a.h <= VOTE_TAB) {
-        if (pin) hipLaunchKernelGGL((k_vote<true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_vote<true, false>), grid, block, 0, s, a);
+        if (pin) hipLaunchKernelGGL((k_vote<true, true>), grid, block, 0, s, b);
+        else hipLaunchKernelGGL((k_vote<true, false>), grid, block, 0, s, b);
     } else {
-        if (pin) hipLaunchKernelGGL((k_vote<false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_vote<false, false>), grid, block, 0, s, a);
+        if (pin) hipLaunchKernelGGL((k_vote<false, true>), grid, block, 0, s, b);
+        else hipLaunchKernelGGL((k_vote<false, false>), grid, block, 0, s, b);
     }
     return hipGetLastError();
 }

@@ -17,13 +17,13 @@ cd /tmp
 python3 "$REPO/bench.py" --steps 20 --warmup 3 $EXTRA > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 echo "bench done"
 # Per-kernel durations: ONE batch in flight (--pipeline 1), so that a launch's duration is that kernel's own time -- the figure
-# bench.py's roofline uses (its HIP-event pass also runs one predictor alone).  With the default two batches in flight
+# bench.py's roofline uses (its HIP-event pass also runs one predictor alone).  With the default four batches in flight
 # kernels of consecutive batches share the chip and every launch takes longer while two run at once; that trace is kept
-# beside it (*_kernel_stats_2inflight.csv) for the record.
+# beside it (*_kernel_stats_inflight.csv) for the record.
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extras --pipeline 1 $EXTRA > "$OUT/${TAG}_stats.log" 2>&1
 cp "$(ls "$OUT/${TAG}_stats"/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_kernel_stats.csv"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats2" -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extras $EXTRA > "$OUT/${TAG}_stats2.log" 2>&1
-cp "$(ls "$OUT/${TAG}_stats2"/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_kernel_stats_2inflight.csv"
+cp "$(ls "$OUT/${TAG}_stats2"/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_kernel_stats_inflight.csv"
 echo "stats done"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
