@@ -685,7 +685,9 @@ hipError_t dh_launch_pixflags(const PixFlagArgs &a, hipStream_t s) {
 #define BOXW_WAVES (BOXW_THREADS / WAVE)
 #define BOX_SPAN 256             // image columns per wave
 #define BOX_MAXR 96              // largest rectangle edge (host: kBoxMaxRect)
-#define BOX_ROWS_IN_FLIGHT 4
+#ifndef BOX_ROWS_IN_FLIGHT
+#define BOX_ROWS_IN_FLIGHT 4     // (measured r02, 256 VGA frames: 2 rows 0.099 ms, 4 rows 0.092, 8 rows 0.090)
+#endif
 
 // AL: 8-byte row loads (w % 4 == 0, 8-byte aligned frames: a lane is all inside or all outside the
 // image); RW4: rw % 4 == 0 (the shifted prefix is read back with one 16-byte LDS load).  Both are
