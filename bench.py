@@ -138,6 +138,14 @@ def main():
     fence = sp.fence
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
 
+    # Priming (initialisation, before the W warm-up steps): every predictor of the pipeline runs each of the two batches once,
+    # so that its first-launch work (lazy module loads, workspace first touch) and the first fill of its box-sum image are
+    # not charged to whichever of the W + K steps happens to be its first.  Reported as config.priming_steps.
+    priming = 0 if args.graph else 2 * depth
+    for _ in range(priming):
+        step()
+    fence()
+    step_no[0] = 0
     for _ in range(args.warmup):
         step()
     fence()
@@ -299,7 +307,7 @@ def main():
                                    f"80x80 patches, 20 mean-shift iterations",
                        "frames_per_gpu": NF, "width": W, "height": H, "trees": args.trees, "max_depth": args.depth,
                        "stride": args.stride, "parallelism": f"frame-sharded x{world}, RCCL all-gather of poses",
-                       "batches_in_flight": depth},
+                       "batches_in_flight": depth, "priming_steps": priming},
             "roofline": roof,
             "repeat_ms_per_step": [round(r, 4) for r in repeats],
             "last_step_batch": "b" if last_was_b else "a",      # which of the two alternating batches the last timed step processed (--dump-poses)
