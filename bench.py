@@ -152,8 +152,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_submitted = time.perf_counter()     # (host side of the K steps: all launches enqueued; the GPU is still working)
     fence()
     elapsed = time.perf_counter() - t0
+    host_submit_ms = (t_submitted - t0) / args.steps * 1e3
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -309,6 +311,7 @@ def main():
                        "stride": args.stride, "parallelism": f"frame-sharded x{world}, RCCL all-gather of poses",
                        "batches_in_flight": depth, "priming_steps": priming},
             "roofline": roof,
+            "host_submit_ms_per_step": round(host_submit_ms, 4),
             "repeat_ms_per_step": [round(r, 4) for r in repeats],
             "last_step_batch": "b" if last_was_b else "a",      # which of the two alternating batches the last timed step processed (--dump-poses)
             "kernels_ms": kernels,
