@@ -92,8 +92,8 @@ class ShardedPredictor:
     `hp` may be ONE predictor or a list of them (pipeline depth = len): consecutive steps then alternate between the
     predictors, each on a stream of its own, so that the latency-bound tail kernels of batch i (vote, mean shift) run
     beside the bandwidth / issue-bound head kernels of batch i + 1 (`dh_predictor` objects are independent: "distinct
-    predictors may run concurrently", include/depthhead_hip.h).  Measured on one MI355X: 505 k -> 549 k frames/s at depth 2,
-    561 k at depth 3 (`tools/two_stream.py`).  Every step still processes one whole batch through every kernel.
+    predictors may run concurrently", include/depthhead_hip.h).  Measured on one MI355X (round 2, final kernels): 513 k frames/s at depth 1,
+    591-613 k at depth 2, 627-657 k at depth 4, no more beyond (`tools/experiments/pipeline_sweep.sh`).  Every step still processes one whole batch through every kernel.
 
     With `backend == "gloo"` (rehearsal on one device, or CPU-only hosts) the records are staged through host memory.
     World size 1: no collective at all."""
