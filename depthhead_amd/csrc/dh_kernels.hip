@@ -5,6 +5,7 @@
 //
 //   k_leaf_prepare  once per forest: everything that depends only on a leaf (vote weight, both
 //                   covariance gates, rotation bins, vote bounding boxes); k_nodes_compact: integer split bounds
+//                   (and, for forests without an ambiguous node, the walk table); k_top_build: the tree tops for LDS
 //   k_boxsum        per batch (uniform-rectangle forests): image of all rectangle sums of a frame, tile flags
 //   k_traverse      per batch: tile of window positions -> region of the rectangle-sum image (or a summed-area
 //                   table) in LDS -> background gate -> root->leaf walk of every (window, tree) -> window list
@@ -18,7 +19,8 @@
 // No MFMA anywhere: there is no dense contraction on this path.  All integer work is exact and
 // order-free (u32 wrapping adds); every floating-point expression is evaluated in the reference's
 // type and order with explicit round-to-nearest intrinsics (no FMA contraction), so results are
-// bit-identical to the CPU restatement in oracle/.
+// bit-identical to the CPU restatement in oracle/.  (One approximation exists, k_vote's v_rcp_f32 quotient: it only picks
+// a cell of the 20 x 20 guess grid when the cell cannot depend on the rounding, and the IEEE divisions decide otherwise.)
 #include "dh_internal.h"
 
 #include <algorithm>
@@ -1250,10 +1252,12 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // ---- phase 3: root->leaf walks.  Work item k = (tree k / n_active, active slot k % n_active),
     // lane = k mod 1024: the lanes of a wave walk the SAME tree for NEIGHBOURING windows (4 px apart),
     // which see almost the same pixels, so they mostly follow the same path: node fetches collapse
-    // to a few addresses per wave and walks end within a level or two of each other.
+    // to a few addresses per wave.  (On the bench forest a third of the walks reach the maximum depth and the rest end
+    // anywhere above it, so a wave's chain runs the full depth while its lanes need half of it.)
     // (Measured and rejected on MI355X, DESIGN.md section 4: a ballot-compacted refill of finished
-    // lanes lengthens this phase by 25-50 % because it breaks exactly that coherence; an LDS cache
-    // of the top tree levels and a persistent launch with per-XCD tile queues gain nothing.)
+    // lanes lengthens this phase by 25-50 % because it breaks exactly that coherence; a persistent launch
+    // with per-XCD tile queues gains nothing.  An LDS copy of the tree tops lost in round 1, when it displaced
+    // tile area under a slower loop; as an 8-byte-per-slot implicit heap it is what walk_absorb uses now.)
     // Trees are validated acyclic on the host, so every walk ends.
     const int total = n_active * T;
     int32_t *wleaf = a.win_leaf + (size_t)frame * a.win_cap * T + wbase;                     // [tree][win_cap] per frame
