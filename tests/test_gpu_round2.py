@@ -664,3 +664,33 @@ def test_ambiguous_threshold_keeps_the_guarded_walks(hp_mod, oracle):
         hp.reserve(2, w, h)
         geo = hp.debug_geometry()
         assert geo["uniform"] == 1 and geo["walk_table"] == 0
+
+
+@pytest.mark.parametrize("size", [(640, 480), (320, 240), (200, 160), (330, 250)])
+def test_vote_cells_at_grid_borders(hp_mod, oracle, size):
+    """k_vote takes the cell of the 20 x 20 guess grid from an approximate quotient unless the quotient lies next to a cell
+    border (frames whose sides are multiples of 20; 330 x 250 is not and always divides).  Here every vote lands ON or within
+    1e-6 .. 1e-2 pixels of a border: a flat frame at z = fx makes the window centre (x - cx, y - cy, fx), so a vote with offset
+    (ox, oy, 0) projects to exactly (x - ox, y - oy) (prediction.rs:647-676), and the offsets put that on multiples of the
+    cell width / height for some windows and a hair beside them for the others.  A one-leaf forest: every window hits it."""
+    from depthhead_amd.forest import NODE_DTYPE, Forest
+    w, h = size
+    K = synth.default_intrinsic(w, h)
+    fx = float(K[0, 0])                                              # (an integer except at 330 x 250, where nothing is exact anyway)
+    frames = np.full((2, h, w), int(round(fx)), dtype=np.uint16)
+    frames[1, :, : w // 2] = 0                                       # second frame: half of it background
+    eps = [0.0, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 3e-4, -3e-4, 1e-3, -1e-3, 1e-2]
+    cw, ch = w / 20.0, h / 20.0
+    # window centres sit at 40 + 4 i: offsets that move them onto / beside multiples of the cell size
+    offs = np.array([[(40 % cw) + 4 * (j % 3) + e, (40 % ch) + 4 * (j % 2) - e, 0.0] for j, e in enumerate(eps)], dtype=np.float32)
+    rots = np.tile(np.array([[0.1, -0.2, 0.3]]), (2, 1))
+    forest = Forest(np.array([~0], dtype=np.int32), np.zeros(0, dtype=NODE_DTYPE), np.array([1.0]),
+                    np.array([0, len(offs)], dtype=np.uint32), np.array([0, len(rots)], dtype=np.uint32), offs, rots)
+    model = synth.ModelParams(stepwidth=4)
+    from test_gpu_parity import _check_frames
+    _check_frames(hp_mod, oracle, forest, model, frames, K, full=True)
+    # the same through a general (non-pinhole) intrinsic matrix: the cell test does not depend on the projection's form
+    K2 = K.copy()
+    K2[0, 1] = 0.25
+    K2[2, 0] = 1e-5
+    _check_frames(hp_mod, oracle, forest, model, frames, K2, full=False)
