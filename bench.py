@@ -464,6 +464,25 @@ def other_configs(args, dev, stream):
     res["c5_320x240_s1_single_frame_graph"] = one(fitted, 1, small, 1, 320, 240, intr_s, graph=True, steps=50)
     c3 = synth.synth_forest(50, 20, synth.FOREST_SEED_BASE + 3)
     res["c3_50x20_s2_32f"] = one(c3, 2, fr256, 32, W, H, intr, steps=3)              # configs[2]: 50 trees, depth 20, stride 2, batch 32
+    # the same config the way the headline is run: four predictors on four streams, batches in flight
+    hps, streams = [], [torch.cuda.Stream(dev) for _ in range(4)]
+    try:
+        for _ in range(4):
+            hps.append(HoughPrediction(c3, synth.ModelParams(stepwidth=2), device=dev.index or 0))
+            hps[-1].reserve(32, W, H)
+        outs = [torch.zeros(32 * 40, dtype=torch.uint8, device=dev) for _ in range(4)]
+
+        def sweep(k):
+            for i in range(k):
+                hps[i % 4].predict_batch_device(fr256.data_ptr(), 32, W, H, intr, outs[i % 4].data_ptr(), stream=streams[i % 4].cuda_stream)
+            torch.cuda.synchronize()
+        sweep(8)
+        t0 = time.perf_counter()
+        sweep(16)
+        res["c3_50x20_s2_32f_4_in_flight"] = round(16 * 32 / (time.perf_counter() - t0), 1)
+    finally:
+        for q in hps:
+            q.close()
     res["unit"] = "frames/s"
     return res
 
