@@ -300,9 +300,11 @@ struct dh_predictor {
     int f_rw = 0, f_rh = 0;
     void *nodes_g = nullptr;     // NodeG[n_nodes]: general-path nodes with integer split bounds (patches up to 255 x 255), else NULL
     void *nodes_u = nullptr;     // 16-byte compact nodes for the current region layout (uniform path)
-    void *nodes_a = nullptr;     // NodeU[n_nodes + 1]: the same nodes as the walk table of walk_absorb (children as byte offsets), or NULL
-    uint32_t *amb_flag = nullptr; // device word: 1 = some node of nodes_u has an ambiguity band (then nodes_a is not used)
-    bool absorb_ok = false;      // no node is ambiguous: the uniform path walks nodes_a
+    void *nodes_a = nullptr;     // NodeU[n_nodes + n_amb + 1]: the same nodes as the walk table of walk_absorb (children as byte offsets), or NULL
+    uint32_t *amb_flag = nullptr; // device word: number of nodes with an ambiguity band (k_nodes_compact's probe pass)
+    uint32_t *amb_list = nullptr; // device: their indices (at most DH_AMB_CAP)
+    uint32_t n_amb = 0;
+    bool absorb_ok = false;      // the uniform path walks nodes_a (at most DH_AMB_CAP ambiguous nodes, table offsets fit 32 bits)
     uint32_t *top_tab = nullptr; // [T][2^top_levels] {offsets, ilo} heap + [T][2^top_levels] entry offsets (k_top_build), copied to LDS by every tile
     int top_levels = 0;
     long long nodes_u_key = 0;   // (ss_row, swizzle) the compact nodes were built for
@@ -533,10 +535,9 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     STEP(dev_alloc(p, &p->kern_ord, DH_GRID3));
     STEP(dev_alloc(p, &p->zeros, 32));
     { uint4 *nu = nullptr; STEP(dev_alloc(p, &nu, p->n_nodes, true)); p->nodes_u = nu; }
-    if (p->n_nodes > 0 && (size_t)p->n_nodes + p->n_leaves < ((size_t)1 << 27) && !p->knobs.no_absorb) {   // (byte offsets into the table stay below 2^31)
-        uint4 *na = nullptr;
-        STEP(dev_alloc(p, &na, (size_t)p->n_nodes + 1, true)); p->nodes_a = na;
+    if (p->n_nodes > 0 && (size_t)p->n_nodes + p->n_leaves + 2 * DH_AMB_CAP < ((size_t)1 << 27) && !p->knobs.no_absorb) {   // (byte offsets into the table stay below 2^31)
         STEP(dev_alloc(p, &p->amb_flag, 1, true));
+        STEP(dev_alloc(p, &p->amb_list, DH_AMB_CAP, true));
     }
     if (rc == DH_OK && prm->subimage_width <= 255 && prm->subimage_height <= 255 && p->n_nodes > 0) {
         // Integer split bounds of the general path (NodeG, see k_traverse): with C_i = max(c_i, 1), delta = (s1 C2 - s2 C1) / (C1 C2)
@@ -578,15 +579,20 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking), "hipStreamCreate");
     if (rc == DH_OK) hipstep(dh_launch_leaf_prepare(d, p->own_stream), "k_leaf_prepare launch");
     if (rc == DH_OK) hipstep(hipStreamSynchronize(p->own_stream), "k_leaf_prepare");
-    if (rc == DH_OK && p->nodes_a && p->f_uniform) {
-        // does any node carry an ambiguity band?  (independent of the region layout: probed once with a dummy one)
-        uint32_t any_amb = 1;
+    if (rc == DH_OK && p->amb_flag && p->f_uniform) {
+        // which nodes carry an ambiguity band?  (independent of the region layout: probed once with a dummy one)
+        uint32_t n_amb = DH_AMB_CAP + 1;
         hipstep(hipMemsetAsync(p->amb_flag, 0, sizeof(uint32_t), p->own_stream), "hipMemset");
-        if (rc == DH_OK) hipstep(dh_launch_nodes_compact(d, 1, 0, 4, (uint32_t)(p->f_rw * p->f_rh), p->nodes_u, nullptr, p->amb_flag, p->own_stream), "k_nodes_compact launch");
-        if (rc == DH_OK) hipstep(hipMemcpyAsync(&any_amb, p->amb_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, p->own_stream), "hipMemcpy");
+        if (rc == DH_OK) hipstep(dh_launch_nodes_compact(d, 1, 0, 4, (uint32_t)(p->f_rw * p->f_rh), nullptr, nullptr, p->amb_flag, p->amb_list, 0, p->own_stream), "k_nodes_compact launch");
+        if (rc == DH_OK) hipstep(hipMemcpyAsync(&n_amb, p->amb_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, p->own_stream), "hipMemcpy");
         if (rc == DH_OK) hipstep(hipStreamSynchronize(p->own_stream), "k_nodes_compact");
-        p->absorb_ok = rc == DH_OK && any_amb == 0;
+        p->absorb_ok = rc == DH_OK && n_amb <= DH_AMB_CAP;
         if (p->absorb_ok) {
+            p->n_amb = n_amb;
+            uint4 *na = nullptr;
+            int r2 = dev_alloc(p, &na, (size_t)p->n_nodes + n_amb + 1, true);
+            if (r2) rc = r2;
+            p->nodes_a = na;
             // levels walked from LDS: as many as keep the copy (12 bytes per heap slot) within 4 KB per workgroup
             int dt = 0;
             while (dt < 6 && (size_t)p->n_trees * (2u << dt) * 12 <= 4096) ++dt;
@@ -595,7 +601,7 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
             p->top_levels = dt;
             if (rc == DH_OK) {
                 uint32_t *tt = nullptr;
-                int r2 = dev_alloc(p, &tt, (size_t)p->n_trees * (1u << dt) * 3, true);
+                r2 = dev_alloc(p, &tt, (size_t)p->n_trees * (1u << dt) * 3, true);
                 if (r2) rc = r2;
                 p->top_tab = tt;
             }
@@ -774,8 +780,8 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     const long long nkey = ((long long)g.ss_row << 32) | ((long long)g.swz_q << 4) | g.swz_log2;
     if (g.npatch > 0 && g.uniform && p->nodes_u_key != nkey) {     // compact nodes carry LDS offsets for this row stride
         hipError_t e = dh_launch_nodes_compact(p->dev, g.ss_row, g.swz_log2, g.swz_q, (uint32_t)(p->f_rw * p->f_rh), p->nodes_u,
-                                               p->absorb_ok ? p->nodes_a : nullptr, nullptr, p->own_stream);
-        if (e == hipSuccess && p->absorb_ok) e = dh_launch_top_build(p->dev, p->nodes_a, p->top_levels, p->top_tab, p->own_stream);
+                                               p->absorb_ok ? p->nodes_a : nullptr, nullptr, p->amb_list, p->n_amb, p->own_stream);
+        if (e == hipSuccess && p->absorb_ok) e = dh_launch_top_build(p->dev, p->nodes_a, p->n_amb, p->top_levels, p->top_tab, p->own_stream);
         if (e == hipSuccess) e = hipStreamSynchronize(p->own_stream);
         if (e != hipSuccess) { free_workspace(p); return fail(DH_EHIP, "k_nodes_compact: %s", hipGetErrorString(e)); }
         p->nodes_u_key = nkey;
@@ -846,7 +852,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.nx = g.nx; ta.ny = g.ny; ta.px = g.px; ta.py = g.py; ta.tiles_x = g.tiles_x; ta.tiles_y = g.tiles_y;
         ta.ss_max = g.ss_max; ta.ss_row = g.ss_row; ta.swz_log2 = g.swz_log2; ta.swz_q = g.swz_q;
         ta.uniform = g.uniform ? 1 : 0; ta.rw = p->f_rw; ta.rh = p->f_rh; ta.area = (uint32_t)(p->f_rw * p->f_rh);
-        ta.nodes_u = p->nodes_u; ta.nodes_a = p->absorb_ok ? p->nodes_a : nullptr; ta.top_tab = p->top_tab; ta.top_levels = p->top_levels; ta.nodes_g = p->knobs.no_general_int ? nullptr : p->nodes_g;
+        ta.nodes_u = p->nodes_u; ta.nodes_a = p->absorb_ok ? p->nodes_a : nullptr; ta.walk_lb = (p->n_nodes + p->n_amb) << 4; ta.amb_list = p->amb_list; ta.top_tab = p->top_tab; ta.top_levels = p->top_levels; ta.nodes_g = p->knobs.no_general_int ? nullptr : p->nodes_g;
         ta.box = box; ta.box_plane = g.box_plane; ta.box_rows = g.box_rows;
         ta.tile_flags = tile_flags;
 #ifdef DH_PROFILING_KNOBS

@@ -109,7 +109,9 @@ struct TraverseArgs {
     int box_plane, box_rows;
     const uint8_t *tile_flags; // [n_frames][tiles] 1 = the tile's region holds a non-zero box sum (k_boxsum) / its footprint a non-zero pixel (k_pixflags)
     const void *nodes_u;    // NodeU[n_nodes], built by k_nodes_compact for this region layout
-    const void *nodes_a;    // uniform path: NodeU[n_nodes + 1] walk table (children as byte offsets; walk_absorb), or NULL
+    const void *nodes_a;    // uniform path: NodeU[n_nodes + n_amb + 1] walk table (children as byte offsets; walk_absorb, k_nodes_compact), or NULL
+    uint32_t walk_lb;        // with nodes_a: byte offset of the entry behind its nodes ((n_nodes + n_amb) << 4); leaf l is walk_lb + 16 l
+    const uint32_t *amb_list; // with nodes_a: the ambiguous nodes (k_nodes_compact)
     const uint32_t *top_tab; // with nodes_a: the first top_levels levels of every tree as an implicit heap + the entries below them (k_top_build)
     int top_levels;
     const void *nodes_g;    // general path: NodeG[n_nodes] with integer split bounds (patches up to 255 x 255), else NULL
@@ -273,7 +275,9 @@ hipError_t dh_launch_mask(const AuxArgs &a, hipStream_t s);
 hipError_t dh_launch_hough2d(const AuxArgs &a, uint16_t *out, hipStream_t s);
 hipError_t dh_kernels_init();
 hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s);
-hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int swz_q, uint32_t area, void *out, void *out_a, uint32_t *any_amb, hipStream_t s);
+hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int swz_q, uint32_t area, void *out, void *out_a, uint32_t *any_amb,
+                                   uint32_t *amb_list, uint32_t n_amb, hipStream_t s);
+#define DH_AMB_CAP 4096      // ambiguous nodes the walk table can hold (more: the guarded node table is walked)
 hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s);
 hipError_t dh_launch_emit(const EmitArgs &a, hipStream_t s);
 hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s);
@@ -284,7 +288,7 @@ hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s);
 hipError_t dh_launch_pixflags(const PixFlagArgs &a, hipStream_t s);
 // rw, rh > 0 selects the uniform (box-sum region) layout, 0 the general (SAT) layout
 size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int top_words, int rw, int rh);
-hipError_t dh_launch_top_build(const DevForest &f, const void *nodes_a, int top_levels, uint32_t *out, hipStream_t s);
+hipError_t dh_launch_top_build(const DevForest &f, const void *nodes_a, uint32_t n_amb, int top_levels, uint32_t *out, hipStream_t s);
 int dh_traverse_row_stride(int px, int step, int sw, int rw);
 // uniform path: column de-interleave factor (log2) for this stride of window positions, plane size, padded row stride
 void dh_traverse_swizzle(int px, int step, int sw, int rw, int *swz_log2, int *swz_q, int *ss_row);

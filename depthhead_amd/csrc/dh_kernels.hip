@@ -221,15 +221,26 @@ struct __attribute__((aligned(16))) NodeU {
     int32_t  child_one;
 };
 
-__global__ void __launch_bounds__(256) k_nodes_compact(const dh_node *nodes, uint32_t n, int ss, int swz_log2, int swz_q, uint32_t area, NodeU *out,
-                                                       NodeU *out_a, uint32_t *any_amb) {
+// Walk table (out_a, optional): the forest's nodes for walk_absorb.  Layout in 16-byte entries:
+//   [0, n)              the internal nodes: {byte offsets of the two box sums (half words), ilo, Zero child, One child}
+//   [n, n + n_amb)      second halves of the AMBIGUOUS nodes (below)
+//   [NB = n + n_amb]    the entry every finished walk re-reads (offsets 0, never greater)
+// Children are byte offsets into the table; leaf l is the virtual offset of entry NB + l, and "ambiguous at the j-th
+// ambiguous node" is the virtual offset of entry NB + n_leaves + j -- anything from entry NB on ends the lock-step loop.
+// A node whose threshold leaves an ambiguity band (ilo, ilo + amb] (amb_list[j] = its index; about two in a million
+// real-valued thresholds, so any forest of a million nodes has some) becomes two entries: the node itself sends D <= ilo to its
+// Zero child and everything else to entry n + j, which sends D > ilo + amb to the One child and the band to the ambiguity
+// code; walk_absorb then decides that one visit with the reference's f64 arithmetic and walks on.
+// any_amb (optional): counts the ambiguous nodes and lists the first DH_AMB_CAP of them in amb_list (the probe pass).
+__global__ void __launch_bounds__(256) k_nodes_compact(const dh_node *nodes, uint32_t n, uint32_t n_leaves, int ss, int swz_log2, int swz_q, uint32_t area, NodeU *out,
+                                                       NodeU *out_a, uint32_t *any_amb, uint32_t *amb_list, uint32_t n_amb) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t NB = n + n_amb;
     if (i >= n) {
-        // walk table (see walk_absorb): entry n is the one every finished walk re-reads (both box-sum offsets 0, never greater)
         if (out_a && i == n) {
             NodeU o;
-            o.offs = 0; o.ilo = INT32_MAX; o.child_zero = o.child_one = (int32_t)(i << 4);
-            out_a[i] = o;
+            o.offs = 0; o.ilo = INT32_MAX; o.child_zero = o.child_one = (int32_t)(NB << 4);
+            out_a[NB] = o;
         }
         return;
     }
@@ -258,23 +269,36 @@ __global__ void __launch_bounds__(256) k_nodes_compact(const dh_node *nodes, uin
     o.ilo = ilo;
     o.child_zero = nd.child_zero;
     o.child_one = nd.child_one;
-    out[i] = o;
-    if (amb && any_amb) atomicOr(any_amb, 1u);
+    if (out) out[i] = o;
+    if (amb && any_amb) {
+        const uint32_t k = atomicAdd(any_amb, 1u);
+        if (k < DH_AMB_CAP && amb_list) amb_list[k] = i;
+    }
     if (out_a) {
-        // walk table: BYTE offsets (two half words) of the two box sums; children as byte offsets into this table, leaf l as the
-        // (virtual) offset of entry n + l -- anything from entry n on means "finished"
         o.offs = (o1 << 2) | (o2 << 18);
-        o.child_zero = (int32_t)((nd.child_zero >= 0 ? (uint32_t)nd.child_zero : n + (uint32_t)~nd.child_zero) << 4);
-        o.child_one = (int32_t)((nd.child_one >= 0 ? (uint32_t)nd.child_one : n + (uint32_t)~nd.child_one) << 4);
+        const uint32_t cz = (nd.child_zero >= 0 ? (uint32_t)nd.child_zero : NB + (uint32_t)~nd.child_zero) << 4;
+        const uint32_t co = (nd.child_one >= 0 ? (uint32_t)nd.child_one : NB + (uint32_t)~nd.child_one) << 4;
+        o.child_zero = (int32_t)cz;
+        o.child_one = (int32_t)co;
+        if (amb) {
+            uint32_t j = 0;
+            while (j < n_amb && amb_list[j] != i) ++j;          // (rare: the few ambiguous nodes search the short list)
+            NodeU o2e = o;
+            o.child_one = (int32_t)((n + j) << 4);
+            o2e.ilo = ilo + (int32_t)amb;
+            o2e.child_zero = (int32_t)((NB + n_leaves + j) << 4);
+            out_a[n + j] = o2e;
+        }
         out_a[i] = o;
     }
 }
 
-hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int swz_q, uint32_t area, void *out, void *out_a, uint32_t *any_amb, hipStream_t s) {
+hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int swz_q, uint32_t area, void *out, void *out_a, uint32_t *any_amb,
+                                   uint32_t *amb_list, uint32_t n_amb, hipStream_t s) {
     if (f.n_nodes == 0) return hipSuccess;
     const uint32_t n = f.n_nodes + (out_a ? 1 : 0);
-    hipLaunchKernelGGL(k_nodes_compact, dim3((n + 255) / 256), dim3(256), 0, s, f.nodes, f.n_nodes, ss, swz_log2, swz_q, area, (NodeU *)out,
-                       (NodeU *)out_a, any_amb);
+    hipLaunchKernelGGL(k_nodes_compact, dim3((n + 255) / 256), dim3(256), 0, s, f.nodes, f.n_nodes, f.n_leaves, ss, swz_log2, swz_q, area, (NodeU *)out,
+                       (NodeU *)out_a, any_amb, amb_list, n_amb);
     return hipGetLastError();
 }
 
@@ -282,24 +306,30 @@ hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int
 // its One child at 2h + 2), each slot = {box-sum byte offsets, ilo} of the node there -- or an absorbing {0, INT32_MAX} when the
 // path to the slot has already ended in a leaf -- followed by the walk-table entry (byte offset into nodes_a) a walk stands at after
 // those DT levels.  Layout: [T][2^DT] uint2 heap (the last slot of a tree unused), then [T][2^DT] uint32 entries.
-__global__ void __launch_bounds__(64) k_top_build(const NodeU *tab, const int32_t *roots, uint32_t n_nodes, uint32_t T, int DT, uint32_t *out) {
+__global__ void __launch_bounds__(64) k_top_build(const NodeU *tab, const int32_t *roots, uint32_t n_nodes, uint32_t n_amb, uint32_t T, int DT, uint32_t *out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    const uint32_t hs = 1u << DT, lb = n_nodes << 4;
+    const uint32_t hs = 1u << DT, second = n_nodes << 4, lb = (n_nodes + n_amb) << 4;
     uint2 *heap = (uint2 *)out + (size_t)t * hs;
     uint32_t *entry = out + (size_t)T * hs * 2 + (size_t)t * hs;
     const int32_t r = roots[t];
     const uint32_t root = r >= 0 ? (uint32_t)r << 4 : lb + ((uint32_t)~r << 4);
     for (uint32_t h = 0; h < 2 * hs - 1; ++h) {
-        // the bits of h + 1 below its leading one spell the path from the root: 0 = Zero child, 1 = One child
+        // the bits of h + 1 below its leading one spell the path from the root: 0 = Zero child, 1 = One child.  The path stops
+        // at a leaf -- and at an ambiguous node (its One child is a second-half entry), which the heap cannot hold: the walk
+        // leaves the tree tops there and takes that node from the table
         uint32_t cur = root;
+        bool stop = false;
         const int len = 31 - __clz((int)(h + 1));
-        for (int b = len - 1; b >= 0 && cur < lb; --b) {
+        for (int b = len; b >= 0 && cur < lb; --b) {
             const NodeU nd = tab[cur >> 4];
-            cur = (uint32_t)((((h + 1) >> b) & 1u) ? nd.child_one : nd.child_zero);
+            const uint32_t one = (uint32_t)nd.child_one;
+            if (one >= second && one < lb) { stop = true; break; }
+            if (b == 0) break;
+            cur = (((h + 1) >> (b - 1)) & 1u) ? one : (uint32_t)nd.child_zero;
         }
         if (h < hs - 1) {
-            const NodeU nd = tab[min(cur, lb) >> 4];          // (entry n reads {0, INT32_MAX}: the path has ended)
+            const NodeU nd = tab[(stop || cur >= lb ? lb : cur) >> 4];   // (entry NB reads {0, INT32_MAX}: the path has ended)
             heap[h] = make_uint2(nd.offs, (uint32_t)nd.ilo);
         } else {
             entry[h - (hs - 1)] = cur;
@@ -308,9 +338,9 @@ __global__ void __launch_bounds__(64) k_top_build(const NodeU *tab, const int32_
     heap[hs - 1] = make_uint2(0u, (uint32_t)INT32_MAX);
 }
 
-hipError_t dh_launch_top_build(const DevForest &f, const void *nodes_a, int top_levels, uint32_t *out, hipStream_t s) {
+hipError_t dh_launch_top_build(const DevForest &f, const void *nodes_a, uint32_t n_amb, int top_levels, uint32_t *out, hipStream_t s) {
     if (f.n_trees == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_top_build, dim3((f.n_trees + 63) / 64), dim3(64), 0, s, (const NodeU *)nodes_a, f.roots, f.n_nodes, f.n_trees, top_levels, out);
+    hipLaunchKernelGGL(k_top_build, dim3((f.n_trees + 63) / 64), dim3(64), 0, s, (const NodeU *)nodes_a, f.roots, f.n_nodes, n_amb, f.n_trees, top_levels, out);
     return hipGetLastError();
 }
 
@@ -922,7 +952,8 @@ __device__ __forceinline__ void walk_absorb(const TraverseArgs &a, const uint32_
                                             const uint32_t *active, const uint32_t *agp, int n_active, int total, int cx, int ss, int T) {
     const int tid = threadIdx.x;
     const char *tab = (const char *)a.nodes_a;
-    const uint32_t lb = a.f.n_nodes << 4;            // byte offset of the first absorbing entry
+    const uint32_t lb = a.walk_lb;                   // byte offset of the entry finished walks re-read; leaf l = lb + 16 l
+    const uint32_t amb_base = lb + (a.f.n_leaves << 4);   // codes "ambiguous at the j-th ambiguous node" (k_nodes_compact)
     const int DT = a.top_levels;
     const uint32_t hs = 1u << DT;
     const char *entries = (const char *)(top + (size_t)T * hs * 2);
@@ -965,24 +996,41 @@ __device__ __forceinline__ void walk_absorb(const TraverseArgs &a, const uint32_
             cur[i] = k0 + i * TRAV_THREADS < total ? e : lb;
         }
         for (;;) {
-            uint32_t mn = cur[0];
+            for (;;) {
+                uint32_t mn = cur[0];
 #pragma unroll
-            for (int i = 1; i < W; ++i) mn = min(mn, cur[i]);
-            if (__ballot(mn < lb) == 0ull) break;
-            uint4 n[W];
+                for (int i = 1; i < W; ++i) mn = min(mn, cur[i]);
+                if (__ballot(mn < lb) == 0ull) break;
+                uint4 n[W];
 #pragma unroll
-            for (int i = 0; i < W; ++i) n[i] = *(const uint4 *)(tab + min(cur[i], lb));   // finished walks all re-read ONE entry: a gather costs by its distinct lines
-            uint32_t s1[W], s2[W];
+                for (int i = 0; i < W; ++i) n[i] = *(const uint4 *)(tab + min(cur[i], lb));   // finished walks all re-read ONE entry: a gather costs by its distinct lines
+                uint32_t s1[W], s2[W];
 #pragma unroll
-            for (int i = 0; i < W; ++i) {
-                s1[i] = *(const uint32_t *)(sp[i] + (n[i].x & 0xffffu));
-                s2[i] = *(const uint32_t *)(sp[i] + (n[i].x >> 16));
+                for (int i = 0; i < W; ++i) {
+                    s1[i] = *(const uint32_t *)(sp[i] + (n[i].x & 0xffffu));
+                    s2[i] = *(const uint32_t *)(sp[i] + (n[i].x >> 16));
+                }
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const uint32_t nx = ((int32_t)s1[i] - (int32_t)s2[i] > (int32_t)n[i].y) ? n[i].w : n[i].z;
+                    cur[i] = cur[i] >= lb ? cur[i] : nx;
+                }
             }
+            // a walk that stands in the ambiguity band of a node (rare: see k_nodes_compact) is decided there by the reference's
+            // own f64 arithmetic (types.rs:338, houghforest.rs:188-191) and walks on
+            bool again = false;
 #pragma unroll
-            for (int i = 0; i < W; ++i) {
-                const uint32_t nx = ((int32_t)s1[i] - (int32_t)s2[i] > (int32_t)n[i].y) ? n[i].w : n[i].z;
-                cur[i] = cur[i] >= lb ? cur[i] : nx;
-            }
+            for (int i = 0; i < W; ++i)
+                if (cur[i] >= amb_base) {
+                    const uint32_t j = (cur[i] - amb_base) >> 4, X = a.amb_list[j];
+                    const uint4 nu = *(const uint4 *)(tab + ((size_t)X << 4)), n2 = *(const uint4 *)(tab + ((size_t)(a.f.n_nodes + j) << 4));
+                    const uint32_t s1 = *(const uint32_t *)(sp[i] + (nu.x & 0xffffu)), s2 = *(const uint32_t *)(sp[i] + (nu.x >> 16));
+                    const double thr = a.f.nodes[X].threshold, c = (double)a.area;
+                    const bool one = __dsub_rn(__ddiv_rn((double)s1, c), __ddiv_rn((double)s2, c)) > thr;
+                    cur[i] = one ? n2.w : nu.z;
+                    again = true;
+                }
+            if (__ballot(again) == 0ull) break;
         }
 #pragma unroll
         for (int i = 0; i < W; ++i)

@@ -647,23 +647,38 @@ def test_walk_table_variants(hp_mod, oracle, knob):
             os.environ.pop(k, None)
 
 
-def test_ambiguous_threshold_keeps_the_guarded_walks(hp_mod, oracle):
-    """One node whose threshold times the rectangle area is an integer has an ambiguity band (k_nodes_compact): the predictor
-    then keeps the guarded node table, whose walks resolve the band with the reference's f64 arithmetic."""
+@pytest.mark.parametrize("where", ["root", "deep", "many", "too many"])
+def test_ambiguous_thresholds_in_the_walk_table(hp_mod, oracle, where):
+    """A node whose threshold times the rectangle area is (within 2^-20 of) an integer has an ambiguity band that only the
+    reference's f64 arithmetic decides (k_nodes_compact).  The walk table carries such a node as two entries and a walk
+    that lands in the band is resolved and walks on -- at the root (inside the tree tops: the walk leaves the LDS heap there),
+    deep in a tree, at hundreds of nodes; beyond DH_AMB_CAP of them the predictor keeps the guarded node table.  Flat frames
+    make every rectangle difference 0, so thresholds of 0 put EVERY visit of such a node into its band."""
     from test_gpu_parity import _check_frames
-    forest = synth.synth_forest(4, 6, 91)
-    nodes = forest.nodes.copy()
-    nodes["threshold"][int(forest.roots[0])] = 3.0
     from depthhead_amd.forest import Forest
+    big = where == "too many"
+    forest = synth.synth_forest(6, 12 if big else 7, 91)
+    nodes = forest.nodes.copy()
+    rs = np.random.RandomState(5)
+    if where == "root":
+        pick = [int(r) for r in forest.roots[:3]]
+    elif where == "deep":
+        pick = [int(i) for i in rs.choice(len(nodes), 5, replace=False)]
+    else:
+        pick = list(range(len(nodes))) if big else [int(i) for i in rs.choice(len(nodes), min(300, len(nodes)), replace=False)]
+    nodes["threshold"][pick] = np.where(rs.rand(len(pick)) < 0.5, 0.0, 3.0)
     forest = Forest(forest.roots, nodes, forest.leaf_prob, forest.off_begin, forest.rot_begin, forest.offsets, forest.rotations)
+    assert not big or len(nodes) > 4096
     model = synth.ModelParams(stepwidth=4)
     w, h = 160, 120
-    frames = synth.biwi_batch(2, w, h, first=5)
+    frames = synth.biwi_batch(3, w, h, first=5)
+    frames[1] = 900                                                   # flat: every difference of two rectangle means is 0
+    frames[2, :, 80:] = 1200
     _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), full=True)
     with hp_mod.HoughPrediction(forest, model, device=0) as hp:
         hp.reserve(2, w, h)
         geo = hp.debug_geometry()
-        assert geo["uniform"] == 1 and geo["walk_table"] == 0
+        assert geo["uniform"] == 1 and geo["walk_table"] == (0 if big else 1)
 
 
 @pytest.mark.parametrize("size", [(640, 480), (320, 240), (200, 160), (330, 250)])
