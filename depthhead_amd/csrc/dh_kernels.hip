@@ -5,7 +5,7 @@
 //
 //   k_leaf_prepare  once per forest: everything that depends only on a leaf (vote weight, both
 //                   covariance gates, rotation bins, vote bounding boxes); k_nodes_compact: integer split bounds
-//                   (and, for forests without an ambiguous node, the walk table); k_top_build: the tree tops for LDS
+//                   and the walk table of the uniform path; k_top_build: its tree tops for LDS
 //   k_boxsum        per batch (uniform-rectangle forests): image of all rectangle sums of a frame, tile flags
 //   k_traverse      per batch: tile of window positions -> region of the rectangle-sum image (or a summed-area
 //                   table) in LDS -> background gate -> root->leaf walk of every (window, tree) -> window list
@@ -937,16 +937,18 @@ __device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32
     }
 }
 
-// The same walks over the walk table nodes_a (k_nodes_compact's second output; used when no node of the forest has an
-// ambiguity band, which the host checks at predictor creation).  What bounds a level of these walks is the 16-byte node gather
-// (vector-memory path and its latency), not the arithmetic -- cutting the loop from 42 to 17 VALU instructions alone changed
-// nothing (profiles/r02_traverse_experiments.md) -- so:
+// The same walks over the walk table nodes_a (k_nodes_compact's second output; used unless the forest has more than
+// DH_AMB_CAP ambiguous nodes).  What bounds a level of these walks is the throughput of the 16-byte node gather, not the
+// arithmetic -- cutting the loop from 42 to 17 VALU instructions alone changed nothing
+// (profiles/r02_traverse_experiments.md, r02_ubench_gather_occ.txt) -- so:
 //  * the first top_levels levels of every tree are walked from an LDS copy (k_top_build: implicit heap, 8-byte slots, no child
 //    pointers), which takes a third of the gathers off that path;
 //  * children are byte offsets into the table (the load needs no address arithmetic), leaf l is the virtual offset of entry
-//    n_nodes + l, and a finished walk re-reads entry n_nodes, the same line for every finished lane: a gather costs by the distinct
+//    NB + l, and a finished walk re-reads entry NB, the same line for every finished lane: a gather costs by the distinct
 //    lines its lanes touch;
-//  * the loop is wave-uniform (no per-walk exec masks): two half-word byte offsets -> two LDS reads, subtract, compare, select.
+//  * the loop is wave-uniform (no per-walk exec masks): two half-word byte offsets -> two LDS reads, subtract, compare, select;
+//  * a walk that lands in the ambiguity band of a node leaves the loop with that node's code, is decided by the reference's
+//    f64 arithmetic and re-enters (rare; the layout is described at k_nodes_compact).
 template <int W>
 __device__ __forceinline__ void walk_absorb(const TraverseArgs &a, const uint32_t *sat, const uint32_t *top, int32_t *wleaf, int32_t *dleaf,
                                             const uint32_t *active, const uint32_t *agp, int n_active, int total, int cx, int ss, int T) {

@@ -252,8 +252,8 @@ int dh_debug_meanshift(dh_predictor *p, int which, int32_t *trace, uint32_t *ste
 /* Per-frame number of (patch, leaf) hit records kept for voting. */
 int dh_debug_hit_counts(dh_predictor *p, uint32_t *out);
 /* Tiling the runtime chose for the current workspace (tests construct edge cases from it):
- * out[0..9] = path (bit 0: uniform-rectangle path; bit 8: its walks use the unguarded walk table, possible when no node has
- * an ambiguity band; bits 16..: tree levels walked from LDS), tile px, py, tiles_x, tiles_y, column de-interleave log2,
+ * out[0..9] = path (bit 0: uniform-rectangle path; bit 8: its walks use the walk table (always, unless the forest has more than 4096
+ * nodes with an ambiguity band); bits 16..: tree levels walked from LDS), tile px, py, tiles_x, tiles_y, column de-interleave log2,
  * plane stride q, LDS row stride, rectangle w, rectangle h. */
 int dh_debug_geometry(dh_predictor *p, int32_t out[10]);
 

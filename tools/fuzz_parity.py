@@ -37,6 +37,16 @@ for case in range(first, first + count):
     forest = synth.synth_forest(trees, depth, 9000 + case, patch=(sw, sh), rect_scale=float(rs.uniform(0.1, 0.6)),
                                 rect_scale_max=float(rs.uniform(0.6, 0.9)) if mixed else None,
                                 full_depth=int(rs.randint(0, depth + 1)), p_split=float(rs.uniform(0.4, 0.95)))
+    # a third of the cases: some thresholds become small integers, whose product with any rectangle area is an integer -- such
+    # nodes have an ambiguity band that only the f64 arithmetic decides (k_nodes_compact), and D = threshold * area is reachable
+    # (own generator: the other draws of a case stay what they were)
+    rs2 = np.random.RandomState((case * 2654435761) & 0x7fffffff)
+    if len(forest.nodes) and rs2.rand() < 0.33:
+        from depthhead_amd.forest import Forest
+        nodes = forest.nodes.copy()
+        pick = rs2.choice(len(nodes), int(rs2.randint(1, len(nodes) + 1)), replace=False)
+        nodes["threshold"][pick] = rs2.randint(-2, 3, len(pick)).astype(np.float64)
+        forest = Forest(forest.roots, nodes, forest.leaf_prob, forest.off_begin, forest.rot_begin, forest.offsets, forest.rotations)
     model = synth.ModelParams(stepwidth=step, subimage_width=sw, subimage_height=sh,
                               gaussian_sigma=float(rs.uniform(0.5, 30.0)), meanshift_iterations=int(rs.randint(0, 25)))
     n = int(rs.randint(1, 4))
