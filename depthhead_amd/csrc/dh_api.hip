@@ -185,6 +185,7 @@ struct Geom {
     int w = 0, h = 0, nx = 0, ny = 0, npatch = 0;
     int px = 0, py = 0, tiles_x = 0, tiles_y = 0, ss_max = 0, ss_row = 0, swz_log2 = 0, swz_q = 0;
     bool uniform = false;       // uniform-rectangle path: k_boxsum feeds k_traverse<true>
+    int top_levels = 0;         // uniform path with the walk table: tree levels walked from the LDS copy of the tree tops
     int flag_words = 0;                // per frame: u32 words holding one flag byte per tile (uniform path)
     int win_cap = 0;                   // slots of a frame's window list: tiles * px * py
     int box_plane = 0, box_rows = 0, box_ow = 0, box_oh = 0, box_parts = 0, box_bands = 0;
@@ -306,7 +307,7 @@ struct dh_predictor {
     uint32_t n_amb = 0;
     bool absorb_ok = false;      // the uniform path walks nodes_a (at most DH_AMB_CAP ambiguous nodes, table offsets fit 32 bits)
     uint32_t *top_tab = nullptr; // [T][2^top_levels] {offsets, ilo} heap + [T][2^top_levels] entry offsets (k_top_build), copied to LDS by every tile
-    int top_levels = 0;
+    int top_levels = 0;          // levels the LDS budget rule gives (choose_tile may add levels that fit beside a thread-capped tile)
     long long nodes_u_key = 0;   // (ss_row, swizzle) the compact nodes were built for
     hipStream_t own_stream = nullptr;
     hipStream_t copy_stream = nullptr;    // host entry points: uploads run here, ahead of the kernels on own_stream
@@ -593,15 +594,20 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
             int r2 = dev_alloc(p, &na, (size_t)p->n_nodes + n_amb + 1, true);
             if (r2) rc = r2;
             p->nodes_a = na;
-            // levels walked from LDS: as many as keep the copy (12 bytes per heap slot) within 4 KB per workgroup
+            // Levels walked from LDS (12 bytes per heap slot).  A small table (the bench forest: 41 KB) is served from L1 / L2 and
+            // every KB of LDS taken from the tile costs halo: 4 KB of tree tops measured best (5 levels at 10 trees; 6 levels
+            // 0.188 vs 0.175 ms).  A table of megabytes (BASELINE config 3: 45 MB) misses the caches, a gather costs 40-60 ns
+            // instead of 7-18 (tools/ubench/gather_occ.hip), and the tree tops are worth a smaller tile: 40 KB (config 3,
+            // 50 trees: 6 levels 0.284 ms, 2 levels 0.365).  choose_tile adds what fits beside a tile for nothing.
+            const size_t top_budget = (size_t)p->n_nodes * 16 > (1u << 20) ? 40 * 1024 : 4 * 1024;
             int dt = 0;
-            while (dt < 6 && (size_t)p->n_trees * (2u << dt) * 12 <= 4096) ++dt;
+            while (dt < 8 && (size_t)p->n_trees * (2u << dt) * 12 <= top_budget) ++dt;
             if (p->knobs.top_levels >= 0) dt = p->knobs.top_levels;
             while (dt > 0 && (size_t)p->n_trees * (1u << dt) * 12 > 48 * 1024) --dt;
             p->top_levels = dt;
             if (rc == DH_OK) {
                 uint32_t *tt = nullptr;
-                r2 = dev_alloc(p, &tt, (size_t)p->n_trees * (1u << dt) * 3, true);
+                r2 = dev_alloc(p, &tt, (size_t)p->n_trees * (1u << 8) * 3, true);      // room for the 8 levels choose_tile may go to
                 if (r2) rc = r2;
                 p->top_tab = tt;
             }
@@ -657,7 +663,8 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
     if (p->knobs.lds_budget_kb > 0) budget = (size_t)p->knobs.lds_budget_kb * 1024;
     budget = std::min<size_t>(budget, 158 * 1024);
     const int fx = p->knobs.tile_x, fy = p->knobs.tile_y;
-    const int top_words = g.uniform && p->absorb_ok ? (int)p->n_trees * (1 << p->top_levels) * 3 : 0;
+    g.top_levels = g.uniform && p->absorb_ok ? p->top_levels : 0;
+    const int top_words = g.uniform && p->absorb_ok ? (int)p->n_trees * (1 << g.top_levels) * 3 : 0;
     long best = -1;
     for (int py = 1; py <= std::min(g.ny, 64); ++py)
         for (int px = 1; px <= std::min(g.nx, 64); ++px) {
@@ -679,6 +686,12 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
         g.lds = dh_traverse_lds_bytes(1, 1, step, sw, sh, top_words, rw, rh);
         if (g.lds > 158 * 1024) return rw > 0 ? 1 : fail(DH_ESIZE, "patch %dx%d with %u trees does not fit LDS", sw, sh, p->n_trees);
     }
+    // a tile capped by its 1024 threads (small strides) or by the frame leaves LDS unused: more tree levels fit for nothing
+    if (g.uniform && p->absorb_ok && p->knobs.top_levels < 0)
+        while (g.top_levels < 8 && g.lds + (size_t)p->n_trees * (1u << g.top_levels) * 12 <= budget) {
+            g.lds += (size_t)p->n_trees * (1u << g.top_levels) * 12;      // (doubling the table adds its current size)
+            ++g.top_levels;
+        }
     g.tiles_x = (g.nx + g.px - 1) / g.px;
     g.tiles_y = (g.ny + g.py - 1) / g.py;
     if ((long)g.tiles_x * g.tiles_y > 65535) return fail(DH_ESIZE, "frame %dx%d needs %ld tiles per frame (limit 65535)", g.w, g.h, (long)g.tiles_x * g.tiles_y);
@@ -777,11 +790,11 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     }
 #undef STEP
     if (rc != DH_OK) { free_workspace(p); return rc; }
-    const long long nkey = ((long long)g.ss_row << 32) | ((long long)g.swz_q << 4) | g.swz_log2;
+    const long long nkey = ((long long)g.ss_row << 32) | ((long long)g.top_levels << 24) | ((long long)g.swz_q << 4) | g.swz_log2;
     if (g.npatch > 0 && g.uniform && p->nodes_u_key != nkey) {     // compact nodes carry LDS offsets for this row stride
         hipError_t e = dh_launch_nodes_compact(p->dev, g.ss_row, g.swz_log2, g.swz_q, (uint32_t)(p->f_rw * p->f_rh), p->nodes_u,
                                                p->absorb_ok ? p->nodes_a : nullptr, nullptr, p->amb_list, p->n_amb, p->own_stream);
-        if (e == hipSuccess && p->absorb_ok) e = dh_launch_top_build(p->dev, p->nodes_a, p->n_amb, p->top_levels, p->top_tab, p->own_stream);
+        if (e == hipSuccess && p->absorb_ok) e = dh_launch_top_build(p->dev, p->nodes_a, p->n_amb, g.top_levels, p->top_tab, p->own_stream);
         if (e == hipSuccess) e = hipStreamSynchronize(p->own_stream);
         if (e != hipSuccess) { free_workspace(p); return fail(DH_EHIP, "k_nodes_compact: %s", hipGetErrorString(e)); }
         p->nodes_u_key = nkey;
@@ -852,7 +865,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.nx = g.nx; ta.ny = g.ny; ta.px = g.px; ta.py = g.py; ta.tiles_x = g.tiles_x; ta.tiles_y = g.tiles_y;
         ta.ss_max = g.ss_max; ta.ss_row = g.ss_row; ta.swz_log2 = g.swz_log2; ta.swz_q = g.swz_q;
         ta.uniform = g.uniform ? 1 : 0; ta.rw = p->f_rw; ta.rh = p->f_rh; ta.area = (uint32_t)(p->f_rw * p->f_rh);
-        ta.nodes_u = p->nodes_u; ta.nodes_a = p->absorb_ok ? p->nodes_a : nullptr; ta.walk_lb = (p->n_nodes + p->n_amb) << 4; ta.amb_list = p->amb_list; ta.top_tab = p->top_tab; ta.top_levels = p->top_levels; ta.nodes_g = p->knobs.no_general_int ? nullptr : p->nodes_g;
+        ta.nodes_u = p->nodes_u; ta.nodes_a = p->absorb_ok ? p->nodes_a : nullptr; ta.walk_lb = (p->n_nodes + p->n_amb) << 4; ta.amb_list = p->amb_list; ta.top_tab = p->top_tab; ta.top_levels = g.top_levels; ta.nodes_g = p->knobs.no_general_int ? nullptr : p->nodes_g;
         ta.box = box; ta.box_plane = g.box_plane; ta.box_rows = g.box_rows;
         ta.tile_flags = tile_flags;
 #ifdef DH_PROFILING_KNOBS
@@ -1659,7 +1672,7 @@ extern "C" int dh_debug_geometry(dh_predictor *p, int32_t out[10]) {
     if (p->cap_frames == 0) return fail(DH_ESTATE, "no workspace yet (dh_predictor_reserve or a batch)");
     const Geom &g = p->geom;
     const bool walk_tab = g.uniform && p->absorb_ok;
-    const int32_t v[10] = {(g.uniform ? 1 : 0) | (walk_tab ? 1 << 8 : 0) | (walk_tab ? p->top_levels << 16 : 0), g.px, g.py, g.tiles_x, g.tiles_y, g.swz_log2, g.swz_q, g.ss_row, p->f_rw, p->f_rh};
+    const int32_t v[10] = {(g.uniform ? 1 : 0) | (walk_tab ? 1 << 8 : 0) | (walk_tab ? g.top_levels << 16 : 0), g.px, g.py, g.tiles_x, g.tiles_y, g.swz_log2, g.swz_q, g.ss_row, p->f_rw, p->f_rh};
     memcpy(out, v, sizeof v);
     return DH_OK;
 }
