@@ -307,7 +307,7 @@ struct dh_predictor {
     uint32_t n_amb = 0;
     bool absorb_ok = false;      // the uniform path walks nodes_a (at most DH_AMB_CAP ambiguous nodes, table offsets fit 32 bits)
     uint32_t *top_tab = nullptr; // [T][2^top_levels] {offsets, ilo} heap + [T][2^top_levels] entry offsets (k_top_build), copied to LDS by every tile
-    int top_levels = 0;          // levels the LDS budget rule gives (choose_tile may add levels that fit beside a thread-capped tile)
+    int top_levels = -1;         // DH_TOP_LEVELS, or -1: choose_tile decides per geometry
     long long nodes_u_key = 0;   // (ss_row, swizzle) the compact nodes were built for
     hipStream_t own_stream = nullptr;
     hipStream_t copy_stream = nullptr;    // host entry points: uploads run here, ahead of the kernels on own_stream
@@ -594,17 +594,7 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
             int r2 = dev_alloc(p, &na, (size_t)p->n_nodes + n_amb + 1, true);
             if (r2) rc = r2;
             p->nodes_a = na;
-            // Levels walked from LDS (12 bytes per heap slot).  A small table (the bench forest: 41 KB) is served from L1 / L2 and
-            // every KB of LDS taken from the tile costs halo: 4 KB of tree tops measured best (5 levels at 10 trees; 6 levels
-            // 0.188 vs 0.175 ms).  A table of megabytes (BASELINE config 3: 45 MB) misses the caches, a gather costs 40-60 ns
-            // instead of 7-18 (tools/ubench/gather_occ.hip), and the tree tops are worth a smaller tile: 40 KB (config 3,
-            // 50 trees: 6 levels 0.284 ms, 2 levels 0.365).  choose_tile adds what fits beside a tile for nothing.
-            const size_t top_budget = (size_t)p->n_nodes * 16 > (1u << 20) ? 40 * 1024 : 4 * 1024;
-            int dt = 0;
-            while (dt < 8 && (size_t)p->n_trees * (2u << dt) * 12 <= top_budget) ++dt;
-            if (p->knobs.top_levels >= 0) dt = p->knobs.top_levels;
-            while (dt > 0 && (size_t)p->n_trees * (1u << dt) * 12 > 48 * 1024) --dt;
-            p->top_levels = dt;
+            p->top_levels = p->knobs.top_levels;          // -1: choose_tile decides per geometry
             if (rc == DH_OK) {
                 uint32_t *tt = nullptr;
                 r2 = dev_alloc(p, &tt, (size_t)p->n_trees * (1u << 8) * 3, true);      // room for the 8 levels choose_tile may go to
@@ -663,7 +653,22 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
     if (p->knobs.lds_budget_kb > 0) budget = (size_t)p->knobs.lds_budget_kb * 1024;
     budget = std::min<size_t>(budget, 158 * 1024);
     const int fx = p->knobs.tile_x, fy = p->knobs.tile_y;
-    g.top_levels = g.uniform && p->absorb_ok ? p->top_levels : 0;
+    // Tree levels walked from LDS (walk_absorb; 12 bytes per heap slot and tree).  LDS given to the tree tops is taken from the
+    // tile, and every tile copies them: 4 KB measured best on the bench workload (10 trees, stride 4: 5 levels 0.175 ms,
+    // 6 levels 0.188) and for 20 trees at stride 4 (4 levels 0.157, 5 levels 0.166, 7 levels 0.191).  More trees mean more walks
+    // per window, and a smaller stride means more windows per byte of region -- both make a level saved worth more LDS:
+    // config 3 (50 trees, stride 2) 6 levels 0.284 ms, 5 levels 0.313, 4 levels 0.343, 2 levels 0.365; config 5 (stride 1) 8 levels.
+    // Hence 200 bytes per tree, scaled by (4 / stride)^2, between 4 and 40 KB; then whatever fits beside the tile for nothing.
+    g.top_levels = 0;
+    if (g.uniform && p->absorb_ok) {
+        if (p->top_levels >= 0) g.top_levels = p->top_levels;
+        else {
+            const double want = 200.0 * p->n_trees * 16.0 / ((double)step * step);
+            const size_t top_budget = (size_t)std::min(40.0 * 1024, std::max(4.0 * 1024, want));
+            while (g.top_levels < 8 && (size_t)p->n_trees * (2u << g.top_levels) * 12 <= top_budget) ++g.top_levels;
+        }
+        while (g.top_levels > 0 && (size_t)p->n_trees * (1u << g.top_levels) * 12 > 48 * 1024) --g.top_levels;
+    }
     const int top_words = g.uniform && p->absorb_ok ? (int)p->n_trees * (1 << g.top_levels) * 3 : 0;
     long best = -1;
     for (int py = 1; py <= std::min(g.ny, 64); ++py)
@@ -687,7 +692,7 @@ static int choose_tile(const dh_predictor *p, Geom &g) {
         if (g.lds > 158 * 1024) return rw > 0 ? 1 : fail(DH_ESIZE, "patch %dx%d with %u trees does not fit LDS", sw, sh, p->n_trees);
     }
     // a tile capped by its 1024 threads (small strides) or by the frame leaves LDS unused: more tree levels fit for nothing
-    if (g.uniform && p->absorb_ok && p->knobs.top_levels < 0)
+    if (g.uniform && p->absorb_ok && p->top_levels < 0)
         while (g.top_levels < 8 && g.lds + (size_t)p->n_trees * (1u << g.top_levels) * 12 <= budget) {
             g.lds += (size_t)p->n_trees * (1u << g.top_levels) * 12;      // (doubling the table adds its current size)
             ++g.top_levels;
