@@ -587,7 +587,8 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
         if (rc == DH_OK) hipstep(dh_launch_nodes_compact(d, 1, 0, 4, (uint32_t)(p->f_rw * p->f_rh), nullptr, nullptr, p->amb_flag, p->amb_list, 0, p->own_stream), "k_nodes_compact launch");
         if (rc == DH_OK) hipstep(hipMemcpyAsync(&n_amb, p->amb_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, p->own_stream), "hipMemcpy");
         if (rc == DH_OK) hipstep(hipStreamSynchronize(p->own_stream), "k_nodes_compact");
-        p->absorb_ok = rc == DH_OK && n_amb <= DH_AMB_CAP;
+        // (the walk table keeps 12 bytes of LDS per tree even with no level in LDS: not for forests of thousands of trees)
+        p->absorb_ok = rc == DH_OK && n_amb <= DH_AMB_CAP && (size_t)p->n_trees * 12 <= 8 * 1024;
         if (p->absorb_ok) {
             p->n_amb = n_amb;
             uint4 *na = nullptr;

@@ -709,3 +709,21 @@ def test_vote_cells_at_grid_borders(hp_mod, oracle, size):
     K2[0, 1] = 0.25
     K2[2, 0] = 1e-5
     _check_frames(hp_mod, oracle, forest, model, frames, K2, full=False)
+
+
+def test_forest_of_very_many_trees_keeps_the_guarded_walks(hp_mod, oracle):
+    """The walk table costs 12 bytes of LDS per tree; a forest of 700 (tiny) trees walks the guarded node table instead."""
+    from test_gpu_parity import _check_frames
+    forest = synth.synth_forest(700, 2, 17)
+    model = synth.ModelParams(stepwidth=8)
+    w, h = 160, 120
+    frames = synth.biwi_batch(1, w, h, first=9)
+    _check_frames(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), full=False)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.reserve(1, w, h)
+        geo = hp.debug_geometry()
+        assert geo["uniform"] == 1 and geo["walk_table"] == 0
+    forest = synth.synth_forest(600, 2, 17)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.reserve(1, w, h)
+        assert hp.debug_geometry()["walk_table"] == 1
