@@ -1681,7 +1681,8 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
     const int frame = blockIdx.y, tid = threadIdx.x;
     uint32_t n = a.hit_count[frame];
     if (n > a.hits_cap) n = a.hits_cap;
-    const uint32_t per = (n + VOTE_SLICES - 1) / VOTE_SLICES;
+    const uint32_t slices = gridDim.x;
+    const uint32_t per = (n + slices - 1) / slices;
     const uint32_t h0 = min(n, blockIdx.x * per), h1 = min(n, h0 + per);
     if (n == 0 || (h0 >= h1 && !a.leaf_hits)) return;       // with the leaf histogram every slice also owns a share of the leaves
     for (int i = tid; i < DH_POSGRID; i += VOTE_THREADS) pos[i] = 0;
@@ -1729,7 +1730,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         // 20^3 guess grid is the sum over the leaves that voted of count x v x (their distinct cells); u32
         // wrap-around makes that the same residue as count separate adds.  The slices share the leaves.
         const uint32_t *lh = a.leaf_hits + (size_t)frame * a.f.n_leaves;
-        for (uint32_t l = blockIdx.x * VOTE_THREADS + tid; l < a.f.n_leaves; l += VOTE_SLICES * VOTE_THREADS) {
+        for (uint32_t l = blockIdx.x * VOTE_THREADS + tid; l < a.f.n_leaves; l += slices * VOTE_THREADS) {
             const uint32_t c = lh[l];
             if (!c) continue;
             const uint4 *tp = (const uint4 *)(a.f.tpl + l);
@@ -1749,7 +1750,10 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
 hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
     if (a.n_frames == 0) return hipSuccess;
     const bool pin = a.k[1] == 0.0f && a.k[3] == 0.0f && a.k[6] == 0.0f && a.k[7] == 0.0f && a.k[8] == 1.0f;
-    const dim3 grid(VOTE_SLICES, a.n_frames), block(VOTE_THREADS);
+    // slices per frame: 8 for batches that fill the chip by their frames, more for small batches (a slice flushes at most
+    // 8 400 cells with atomics, so 64 slices of one frame still cost less than a mostly idle chip)
+    const uint32_t slices = a.n_frames >= 128 ? VOTE_SLICES : std::min(64u, std::max((uint32_t)VOTE_SLICES, 1024u / (uint32_t)a.n_frames));
+    const dim3 grid(slices, a.n_frames), block(VOTE_THREADS);
     VoteArgs b = a;
     b.cell_fast = a.cell_fast && a.w % DH_GRID == 0 && a.h % DH_GRID == 0 && a.w > 0 && a.h > 0;
     b.sx = (float)DH_GRID / (float)a.w; b.sy = (float)DH_GRID / (float)a.h;
