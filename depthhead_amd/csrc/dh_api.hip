@@ -248,6 +248,7 @@ struct Knobs {
     int region_min_hits = 0;          // DH_REGION_MIN_HITS: hit records in a frame from which k_region pre-gathers its first regions (small batches);
                                       //   0 = automatic: 8192 for forests without leaf histogram (their rotation gather costs ~9 ns a record), 65536 with
     int top_levels = -1;              // DH_TOP_LEVELS: tree levels walked from the LDS copy of the tree tops (-1 = auto, 0 = none)
+    bool no_tile_list = false;        // DH_NO_TILE_LIST: k_traverse launches a workgroup per tile position, empty ones included, in place
     bool vote_exact = false;          // DH_VOTE_EXACT: k_vote takes the two IEEE divisions for every vote (no approximate-quotient cell test)
     bool no_absorb = false;           // DH_NO_ABSORB: uniform path walks the guarded node table even when no node is ambiguous
     bool no_general_int = false;      // DH_NO_GENERAL_INT: general path with the f64 divisions on every visit
@@ -277,6 +278,7 @@ static Knobs read_knobs() {
     k.no_general_int = getenv("DH_NO_GENERAL_INT") != nullptr;
     k.no_absorb = getenv("DH_NO_ABSORB") != nullptr;
     k.vote_exact = getenv("DH_VOTE_EXACT") != nullptr;
+    k.no_tile_list = getenv("DH_NO_TILE_LIST") != nullptr;
     if (const char *e = getenv("DH_TOP_LEVELS")) k.top_levels = std::max(0, std::min(8, atoi(e)));
     k.stage_chunk = std::max(1, geti("DH_STAGE_CHUNK", 64));
     k.host_threads = std::max(1, std::min(64, geti("DH_HOST_THREADS", (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())))));
@@ -332,6 +334,8 @@ struct dh_predictor {
     HitBox *hit_box = nullptr;
     HitRot *hit_rot = nullptr;
     uint32_t *box = nullptr;         // [cap][box_rows][m][box_plane] rectangle-sum images (uniform path)
+    uint32_t *tile_list = nullptr;  // [DH_MAX_CHUNKS][8][ceil(cap / 8) * tiles] + [DH_MAX_CHUNKS][8] counts behind it (k_tile_list)
+    size_t tile_list_stride = 0;    // entries per x
     unsigned long long *box_mask = nullptr;   // [cap][ceil(box_rows / 32)][box_parts] which lanes wrote non-zero sums last time (BoxArgs::blk_mask)
     uint32_t *win_patch = nullptr;   // [cap][win_cap] window list: position in the window grid
     int32_t *win_leaf = nullptr;     // [cap][T][win_cap] window list: leaf per tree
@@ -434,11 +438,11 @@ static void drop_graph(dh_predictor *p) {
 static void free_workspace(dh_predictor *p) {
     // a captured batch has the old workspace pointers baked in: replaying it would touch freed memory
     if (p->graph_exec) { drop_graph(p); p->graph_stale = true; }
-    void *ptrs[] = {p->box_mask, p->pre_region, p->box, p->win_patch, p->win_leaf, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
+    void *ptrs[] = {p->tile_list, p->box_mask, p->pre_region, p->box, p->win_patch, p->win_leaf, p->aux_leaf, p->aux_flags, p->aux_u32, p->aux_out, p->ws_frames, p->hits, p->hit_box, p->hit_rot, p->counters, p->ws_poses, p->ws_midp, p->ws_rot, p->ws_mask, p->dbg_leaf,
                     p->dbg_flags, p->dbg_guess, p->dbg_trace, p->dbg_steps, p->dbg_votes, p->dbg_vcount};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    p->pre_region = nullptr; p->pre_cap = 0; p->box_mask = nullptr;
+    p->pre_region = nullptr; p->pre_cap = 0; p->box_mask = nullptr; p->tile_list = nullptr; p->tile_list_stride = 0;
     p->box = nullptr; p->win_patch = nullptr; p->win_leaf = nullptr; p->leaf_hits = nullptr; p->zero_words = 0;
     p->aux_leaf = nullptr; p->aux_flags = nullptr; p->aux_u32 = nullptr; p->aux_out = nullptr; p->aux_out_bytes = 0; p->aux_cap = 0;
     p->ws_frames = nullptr; p->hits = nullptr; p->hit_box = nullptr; p->hit_rot = nullptr; p->counters = nullptr; p->ws_poses = nullptr; p->ws_midp = nullptr;
@@ -766,6 +770,10 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     }
     STEP(dev_alloc(p, &p->win_patch, (size_t)cap * std::max(g.win_cap, 1)));
     STEP(dev_alloc(p, &p->win_leaf, (size_t)cap * std::max(g.win_cap, 1) * p->n_trees));
+    if (!p->knobs.no_tile_list && g.npatch > 0) {
+        p->tile_list_stride = (size_t)((cap + 7) / 8) * g.tiles_x * g.tiles_y;
+        if (p->tile_list_stride < ((size_t)1 << 31)) STEP(dev_alloc(p, &p->tile_list, (size_t)DH_MAX_CHUNKS * 8 * (p->tile_list_stride + 1)));
+    }
     if (g.uniform) {
         const size_t words = (size_t)cap * g.box_rows * ((size_t)g.box_plane << g.swz_log2);
         STEP(dev_alloc(p, &p->box, words));
@@ -819,7 +827,7 @@ extern "C" int dh_predictor_reserve(dh_predictor *p, int n, int w, int h) {
 static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n, int w, int h, const float K[9],
                          const float kinv[9], const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
                          dh_pose *out, hipStream_t s, bool profile, int32_t *leaf_out = nullptr, uint8_t *flags_out = nullptr,
-                         bool traverse_only = false) {
+                         bool traverse_only = false, int chunk = 0) {
     const Geom &g = p->geom;
     uint32_t *hit_count = p->counters + f0;
     uint32_t *pos_grid = p->counters + p->cap_frames + (size_t)f0 * DH_POSGRID;
@@ -895,6 +903,13 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.win_patch = p->win_patch + (size_t)f0 * g.win_cap; ta.win_leaf = p->win_leaf + (size_t)f0 * g.win_cap * p->n_trees;
         ta.dbg_leaf = leaf_out ? leaf_out : p->debug ? p->dbg_leaf + (size_t)f0 * g.npatch * p->n_trees : nullptr;
         ta.dbg_flags = flags_out ? flags_out : p->debug ? p->dbg_flags + (size_t)f0 * g.npatch : nullptr;
+        // product mode: the flagged tiles as compact lists, so that the workgroups of empty tiles sit at the end of the grid
+        // (with the taps on, every tile position keeps its workgroup: those of empty tiles write the taps' "background")
+        if (p->tile_list && !ta.dbg_leaf && !ta.dbg_flags) {
+            uint32_t *lst = p->tile_list + (size_t)chunk * 8 * (p->tile_list_stride + 1), *cnt = lst + 8 * p->tile_list_stride;
+            HIP_TRY(dh_launch_tile_list(tile_flags, n, tiles, lst, cnt, (uint32_t)p->tile_list_stride, s));
+            ta.tile_list = lst; ta.tile_list_count = cnt; ta.tile_list_stride = (uint32_t)p->tile_list_stride;
+        }
         HIP_TRY(dh_launch_traverse(ta, g.lds, s));
         if (profile) HIP_TRY(hipEventRecord(p->ev[5], s));
         if (!traverse_only) {
@@ -1008,7 +1023,7 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
                 const int c0 = (int)((long long)m * c / chunks), c1 = (int)((long long)m * (c + 1) / chunks);
                 hipStream_t cs = c == 0 ? s : p->aux_stream[c - 1];
                 if (c > 0) HIP_TRY(hipStreamWaitEvent(cs, p->ev_fork, 0));
-                rc = enqueue_range(p, fr, c0, c1 - c0, w, h, K, kinv, mg, rg, gm, out + f0, cs, false);
+                rc = enqueue_range(p, fr, c0, c1 - c0, w, h, K, kinv, mg, rg, gm, out + f0, cs, false, nullptr, nullptr, false, c);
                 if (rc) return rc;
                 if (c > 0) {
                     HIP_TRY(hipEventRecord(p->ev_join[c - 1], cs));

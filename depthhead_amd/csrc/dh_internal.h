@@ -107,6 +107,9 @@ struct TraverseArgs {
     int swz_log2, swz_q;    // uniform path: LDS slot of region cell (y, x) = y * ss_row + (x & (m - 1)) * swz_q + (x >> swz_log2), m = 1 << swz_log2
     const uint32_t *box;    // uniform path: [n_frames][box_rows][m planes][box_plane] box-sum images written by k_boxsum
     int box_plane, box_rows;
+    const uint32_t *tile_list;       // nullable: [8][tile_list_stride] the flagged (frame group << 16 | tile) pairs per x = frame mod 8 (k_tile_list)
+    const uint32_t *tile_list_count; // [8]
+    uint32_t tile_list_stride;
     const uint8_t *tile_flags; // [n_frames][tiles] 1 = the tile's region holds a non-zero box sum (k_boxsum) / its footprint a non-zero pixel (k_pixflags)
     const void *nodes_u;    // NodeU[n_nodes], built by k_nodes_compact for this region layout
     const void *nodes_a;    // uniform path: NodeU[n_nodes + n_amb + 1] walk table (children as byte offsets; walk_absorb, k_nodes_compact), or NULL
@@ -279,6 +282,7 @@ hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int
                                    uint32_t *amb_list, uint32_t n_amb, hipStream_t s);
 #define DH_AMB_CAP 4096      // ambiguous nodes the walk table can hold (more: the guarded node table is walked)
 hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s);
+hipError_t dh_launch_tile_list(const uint8_t *flags, int n_frames, int tiles, uint32_t *list, uint32_t *count, uint32_t stride, hipStream_t s);
 hipError_t dh_launch_emit(const EmitArgs &a, hipStream_t s);
 hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s);
 hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s);

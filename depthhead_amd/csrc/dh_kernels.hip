@@ -344,6 +344,40 @@ hipError_t dh_launch_top_build(const DevForest &f, const void *nodes_a, uint32_t
     return hipGetLastError();
 }
 
+// ================================================================== k_tile_list
+// Which (frame, tile) pairs does k_traverse have to work on?  One list per x = frame mod 8 (the grid's x, which picks the XCD),
+// in the order the grid visits them (frame group, then tile), entry = group << 16 | tile.  k_traverse's workgroup (x, k) takes the
+// k-th entry; the workgroups beyond a list's end -- the flagged-empty tiles, four in seven on the bench frames -- then sit at the
+// END of the grid, where they leave at once instead of each holding a workgroup slot (79 KB of LDS) for the 1-2 us it takes a
+// workgroup to start, read its flag and go, in the middle of the real work.
+__global__ void __launch_bounds__(1024) k_tile_list(const uint8_t *flags, int n_frames, int tiles, uint32_t *list, uint32_t *count, uint32_t stride) {
+    __shared__ uint32_t wsum[16];
+    const int x = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+    const uint32_t fb = (uint32_t)(n_frames + 7) / 8, total = fb * (uint32_t)tiles;
+    uint32_t base = 0;
+    for (uint32_t e0 = 0; e0 < total; e0 += 1024) {
+        const uint32_t e = e0 + (uint32_t)tid;
+        const uint32_t z = e / (uint32_t)tiles, t = e - z * (uint32_t)tiles;
+        const uint32_t frame = z * 8 + (uint32_t)x;
+        const bool on = e < total && frame < (uint32_t)n_frames && flags[(size_t)frame * tiles + t] != 0;
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) wsum[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
+        for (int i = 0; i < 16; ++i) { const uint32_t c = wsum[i]; off += i < wv ? c : 0u; tot += c; }
+        if (on) list[(size_t)x * stride + base + off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (z << 16) | t;
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) count[x] = base;
+}
+
+hipError_t dh_launch_tile_list(const uint8_t *flags, int n_frames, int tiles, uint32_t *list, uint32_t *count, uint32_t stride, hipStream_t s) {
+    if (n_frames == 0 || tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tile_list, dim3(8), dim3(1024), 0, s, flags, n_frames, tiles, list, count, stride);
+    return hipGetLastError();
+}
+
 // ================================================================== k_traverse
 // One 1024-thread workgroup per tile of PX x PY sliding-window positions of one frame: build the
 // tile's image in LDS, gate out background windows, walk every tree for the active windows, write
@@ -1143,8 +1177,15 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // walks whole frames and the overlapping tile halos of a frame are re-read from one L2.
     // The grid is (8, tiles, frames / 8): the linear workgroup id -- which the hardware deals out to the
     // XCDs round-robin -- is x + 8 * (tile + tiles * z), so no division is needed to decode it.
-    const int frame = (int)blockIdx.z * 8 + (int)blockIdx.x;
-    const int tile = (int)blockIdx.y;
+    int frame = (int)blockIdx.z * 8 + (int)blockIdx.x;
+    int tile = (int)blockIdx.y;
+    if (a.tile_list) {
+        // (k_tile_list) this workgroup takes the k-th flagged tile of the frames = x mod 8; both loads at once
+        const uint32_t k = blockIdx.y + gridDim.y * blockIdx.z;
+        const uint32_t e = a.tile_list[(size_t)blockIdx.x * a.tile_list_stride + k], cnt = a.tile_list_count[blockIdx.x];
+        if (k >= cnt) return;
+        frame = (int)(e >> 16) * 8 + (int)blockIdx.x; tile = (int)(e & 0xffffu);
+    }
     if (frame >= a.n_frames || KNOB_STOP(a.stop_phase == 9)) return;
     const int ty = div_small(tile, a.tiles_x, 1.0f / (float)a.tiles_x), tx = tile - ty * a.tiles_x;
     const int cx = min(a.px, a.nx - tx * a.px), cy = min(a.py, a.ny - ty * a.py);
@@ -1174,7 +1215,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // k_boxsum (uniform path) / k_pixflags (general path) flagged the tiles whose region holds a non-zero
     // rectangle sum / whose footprint holds a non-zero pixel; any other tile has only background windows
     // (prediction.rs:567-576) and leaves before building anything
-    bool nonzero = a.tile_flags[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] != 0;
+    bool nonzero = a.tile_list != nullptr || a.tile_flags[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] != 0;
     if (tid < 8) misc[tid] = 0;
     if (!UNI) __syncthreads();        // (the uniform path's copy ends with a barrier before misc is used)
     if (UNI && nonzero) {

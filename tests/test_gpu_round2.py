@@ -727,3 +727,29 @@ def test_forest_of_very_many_trees_keeps_the_guarded_walks(hp_mod, oracle):
     with hp_mod.HoughPrediction(forest, model, device=0) as hp:
         hp.reserve(1, w, h)
         assert hp.debug_geometry()["walk_table"] == 1
+
+
+@pytest.mark.parametrize("general", [False, True])
+@pytest.mark.parametrize("knob", [None, "DH_NO_TILE_LIST"])
+def test_flagged_tile_lists_in_product_mode(hp_mod, oracle, general, knob):
+    """Product mode hands k_traverse the flagged tiles as compact lists (k_tile_list), one per frame mod 8: frames that are
+    empty, all noise (every tile flagged), a blob in one corner, ordinary subjects; 11 and 3 frames (not multiples of 8);
+    uniform and general path; and the same with a workgroup per tile position (DH_NO_TILE_LIST)."""
+    forest = synth.fit_forest(6, 9, synth.FOREST_SEED_BASE + 83, n_frames=10, subset=1500)
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 320, 240
+    frames = synth.biwi_batch(11, w, h, first=600)
+    rs = np.random.RandomState(8)
+    frames[1] = 0
+    frames[4] = rs.randint(400, 1400, (h, w)).astype(np.uint16)
+    frames[6] = 0
+    frames[6, 200:, 280:] = 900
+    frames[9] = 0
+    frames[10, :, :160] = 0
+    env = {}
+    if general:
+        env["DH_FORCE_GENERAL"] = "1"
+    if knob:
+        env[knob] = "1"
+    _product_mode_check(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h), env=env)
+    _product_mode_check(hp_mod, oracle, forest, model, frames[3:6], synth.default_intrinsic(w, h), env=env)
