@@ -871,6 +871,12 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         fa.tfh = (g.py - 1) * (int)p->params.stepwidth + (int)p->params.subimage_height;
         HIP_TRY(dh_launch_pixflags(fa, s));
     }
+    // product mode: the flagged tiles as compact lists, so that the workgroups of empty tiles sit at the end of k_traverse's grid
+    // (with the taps on, every tile position keeps its workgroup: those of empty tiles write the taps' "background")
+    const bool use_list = p->tile_list && g.npatch > 0 && !leaf_out && !flags_out && !p->debug;
+    uint32_t *tl_list = use_list ? p->tile_list + (size_t)chunk * 8 * (p->tile_list_stride + 1) : nullptr;
+    uint32_t *tl_count = use_list ? tl_list + 8 * p->tile_list_stride : nullptr;
+    if (use_list) HIP_TRY(dh_launch_tile_list(tile_flags, n, g.tiles_x * g.tiles_y, tl_list, tl_count, (uint32_t)p->tile_list_stride, s));
     if (profile) HIP_TRY(hipEventRecord(p->ev[4], s));
     if (g.npatch > 0) {
         TraverseArgs ta{};
@@ -903,13 +909,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.win_patch = p->win_patch + (size_t)f0 * g.win_cap; ta.win_leaf = p->win_leaf + (size_t)f0 * g.win_cap * p->n_trees;
         ta.dbg_leaf = leaf_out ? leaf_out : p->debug ? p->dbg_leaf + (size_t)f0 * g.npatch * p->n_trees : nullptr;
         ta.dbg_flags = flags_out ? flags_out : p->debug ? p->dbg_flags + (size_t)f0 * g.npatch : nullptr;
-        // product mode: the flagged tiles as compact lists, so that the workgroups of empty tiles sit at the end of the grid
-        // (with the taps on, every tile position keeps its workgroup: those of empty tiles write the taps' "background")
-        if (p->tile_list && !ta.dbg_leaf && !ta.dbg_flags) {
-            uint32_t *lst = p->tile_list + (size_t)chunk * 8 * (p->tile_list_stride + 1), *cnt = lst + 8 * p->tile_list_stride;
-            HIP_TRY(dh_launch_tile_list(tile_flags, n, tiles, lst, cnt, (uint32_t)p->tile_list_stride, s));
-            ta.tile_list = lst; ta.tile_list_count = cnt; ta.tile_list_stride = (uint32_t)p->tile_list_stride;
-        }
+        if (use_list) { ta.tile_list = tl_list; ta.tile_list_count = tl_count; ta.tile_list_stride = (uint32_t)p->tile_list_stride; }
         HIP_TRY(dh_launch_traverse(ta, g.lds, s));
         if (profile) HIP_TRY(hipEventRecord(p->ev[5], s));
         if (!traverse_only) {

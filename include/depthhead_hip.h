@@ -106,7 +106,7 @@ typedef struct dh_timing {
     float cluster_ms;  /* initial guesses + both mean shifts                 */
     float total_ms;    /* first kernel start -> last kernel end              */
     uint32_t n_frames;
-    float boxsum_ms;   /* rectangle-sum images (uniform-rectangle forests only, else 0) */
+    float boxsum_ms;   /* rectangle-sum images or pixel flags, and the list of flagged tiles */
     float emit_ms;     /* probability gate + hit records                     */
     uint32_t reserved;
 } dh_timing;
