@@ -77,6 +77,12 @@ for case in range(first, first + count):
             leaf = hp.debug_leaf_indices(n, w, h)
             pg, rg = hp.debug_grids(n)
             hits_total += int(hp.debug_hit_counts(n).sum())
+            # product mode (taps off: flagged-tile lists, no workgroups for empty tiles) must give the same poses
+            hp.debug_enable(False)
+            if hp.predict_batch(frames.astype(np.uint16), IntrinsicMatrix(K), midp, rot).tobytes() != poses.tobytes():
+                bad += 1
+                print(f"MISMATCH case {case}: product mode differs from the run with the taps on")
+            hp.debug_enable(True)
             if api:                                   # (after the taps: these runs invalidate them)
                 masks = hp.predict_mask(frames.astype(np.uint16))
                 hough = hp.build_hough_votes(frames.astype(np.uint16), IntrinsicMatrix(K))

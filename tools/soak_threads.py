@@ -34,9 +34,12 @@ def work(t):
                 else:
                     if not np.array_equal(hp.predict_mask(frames[:3]), rmask):
                         bad[t] += 1
+                        errs.append((t, it, "predict_mask"))
                     continue
                 if not (np.array_equal(out["mid_point"], ref["mid_point"][idx]) and np.array_equal(out["rotation"], ref["rotation"][idx])):
                     bad[t] += 1
+                    wrong = [int(j) for j in range(len(idx)) if not (np.array_equal(out["mid_point"][j], ref["mid_point"][idx[j]]) and np.array_equal(out["rotation"][j], ref["rotation"][idx[j]]))]
+                    errs.append((t, it, "predict_batch" if k == 0 else "predict_batch_rle", len(idx), wrong[:8], [int(idx[j]) for j in wrong[:8]]))
     except Exception as e:   # noqa
         errs.append((t, repr(e)))
 
