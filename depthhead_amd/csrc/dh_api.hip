@@ -777,14 +777,17 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     if (g.uniform) {
         const size_t words = (size_t)cap * g.box_rows * ((size_t)g.box_plane << g.swz_log2);
         STEP(dev_alloc(p, &p->box, words));
-        if (rc == DH_OK && hipMemset(p->box, 0, words * sizeof(uint32_t)) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box)");   // the slack columns stay 0
+        // (the slack columns stay 0.  Zero-fills of a new workspace are ordered explicitly: issued on the predictor's stream and
+        // waited for below -- the streams here are non-blocking ones, which the legacy stream of a plain hipMemset does not order)
+        if (rc == DH_OK && hipMemsetAsync(p->box, 0, words * sizeof(uint32_t), p->own_stream) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box)");
         if (!p->knobs.box_dense) {
             // zeroed together with the images: "cell non-zero => mask bit set" holds from the start
             const size_t mw = (size_t)cap * ((g.box_rows + 31) / 32) * g.box_parts;
             STEP(dev_alloc(p, &p->box_mask, mw));
-            if (rc == DH_OK && hipMemset(p->box_mask, 0, mw * sizeof(unsigned long long)) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box_mask)");
+            if (rc == DH_OK && hipMemsetAsync(p->box_mask, 0, mw * sizeof(unsigned long long), p->own_stream) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box_mask)");
         }
     }
+    if (rc == DH_OK && hipStreamSynchronize(p->own_stream) != hipSuccess) rc = fail(DH_EHIP, "zero-fill of the rectangle-sum images");
     // one block, one memset per batch: hit counters | guess grids | tile flags | window counts | leaf histogram
     const size_t counter_words = (size_t)cap * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words + (size_t)g.tiles_x * g.tiles_y);
     STEP(dev_alloc(p, &p->counters, counter_words + (leaf_hist ? (size_t)cap * p->n_leaves : 0) + 4));   // (+4: the zero-fill kernel rounds up to 16 bytes)
