@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=None,
+                    help="frames per GPU per step; default 256 (BASELINE configs[1]), and 512 with --gpus 8 (configs[3]: 4 096 frames over 8 GPUs)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--trees", type=int, default=10)
@@ -60,12 +61,17 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (other configs, PCIe-inclusive rates): profiling runs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
     ap.add_argument("--pipeline", type=int, default=4, help="batches in flight per GPU (predictors / streams that consecutive steps alternate between)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the per-step all-gather even with ONE rank (launch through "
+                         "torch.distributed.run --nproc-per-node 1): executes the RCCL path on a one-GPU box")
     ap.add_argument("--dump-poses", default=None, help="rank 0 writes the gathered pose records of the last timed step (all ranks, rank order) as .npy")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    if args.frames is None:
+        args.frames = 512 if args.gpus == 8 else 256
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -82,9 +88,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
         else:
@@ -125,7 +134,7 @@ def main():
     # the shard -> predict -> gather loop is the package's (depthhead_amd.dist.ShardedPredictor): two pose buffers, the
     # RCCL all-gather of step i overlaps the kernels of step i + 1
     from depthhead_amd.dist import ShardedPredictor
-    sp = ShardedPredictor(hps, NF, W, H, intr, device=dev)
+    sp = ShardedPredictor(hps, NF, W, H, intr, device=dev, force_collective=args.force_dist)
     poses = sp.pose_bufs[0]
     if args.graph:
         sp.capture(frames.data_ptr())
@@ -133,7 +142,8 @@ def main():
     def step():
         i = step_no[0]
         step_no[0] += 1
-        sp.submit((frames if args.graph else batches[(i // depth) % 2]).data_ptr(), stream)
+        # (the frames are resident and nothing is pending on `stream`: deeper pipelines need not wait for it)
+        sp.submit((frames if args.graph else batches[(i // depth) % 2]).data_ptr(), stream if depth == 1 else None)
 
     fence = sp.fence
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
@@ -156,7 +166,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     host_submit_ms = (t_submitted - t0) / args.steps * 1e3
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -175,7 +185,7 @@ def main():
                 step()
             fence()
             e = time.perf_counter() - tr
-            if world > 1:
+            if dist is not None:
                 t = torch.tensor([e], dtype=torch.float64, device=gdev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 e = float(t.item())
@@ -302,14 +312,16 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32/f64",
-            "data": "synthetic (two different 256-frame batches per GPU, alternating)",
-            "config": {"workload": f"BASELINE configs[1]: {NF} synthetic {W}x{H} u16 depth frames per GPU, "
+            "data": f"synthetic (two different {NF}-frame batches per GPU, alternating)",
+            "config": {"workload": f"{workload_name(args, world, NF)}: {NF} synthetic {W}x{H} u16 depth frames per GPU, "
                                    f"{args.trees}-tree depth-{args.depth} {args.forest} synthetic forest "
                                    f"({forest.n_nodes} nodes, {forest.n_leaves} leaves), stride-{args.stride} "
                                    f"80x80 patches, 20 mean-shift iterations",
                        "frames_per_gpu": NF, "width": W, "height": H, "trees": args.trees, "max_depth": args.depth,
                        "stride": args.stride, "parallelism": f"frame-sharded x{world}, RCCL all-gather of poses",
-                       "batches_in_flight": depth, "priming_steps": priming},
+                       "batches_in_flight": depth, "priming_steps": priming,
+                       "collective": ("RCCL all_gather_into_tensor of the pose records every step" if sp.collective and args.backend == "nccl"
+                                      else "gloo all-gather through host memory (rehearsal)" if sp.collective else "none (one rank, no process group)")},
             "roofline": roof,
             "host_submit_ms_per_step": round(host_submit_ms, 4),
             "repeat_ms_per_step": [round(r, 4) for r in repeats],
@@ -345,9 +357,19 @@ def main():
     if hp is not None:
         for q in hps:
             q.close()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def workload_name(args, world: int, nf: int) -> str:
+    """Which BASELINE.json config the job as a whole is."""
+    if (args.width, args.height, args.trees, args.depth, args.stride) == (640, 480, 10, 15, 4):
+        if world == 8 and nf == 512:
+            return "BASELINE configs[3] (4 096-frame stream frame-sharded over 8 GPUs, 512 per rank; per GPU the configs[1] geometry)"
+        if nf == 256:
+            return "BASELINE configs[1]"
+    return "custom workload"
 
 
 WORKLOAD_FLAGS = ("--frames", "--width", "--height", "--trees", "--depth", "--stride", "--forest", "--graph")
@@ -361,8 +383,11 @@ def kernel_source_hash() -> str:
     """Identifies the kernels a profile was taken on: sha256 over the kernel / runtime sources."""
     import hashlib
     h = hashlib.sha256()
-    for fn in ("dh_kernels.hip", "dh_api.hip", "dh_internal.h"):
-        h.update(open(os.path.join(ROOT, "depthhead_amd", "csrc", fn), "rb").read())
+    csrc = os.path.join(ROOT, "depthhead_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(csrc, fn), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -5,173 +5,38 @@
 // Sits where HoughPrediction::predict_parameter_generic sits in the reference
 // (src/hough/prediction.rs:421-493); the unit of work is a batch of frames.
 #include <math.h>
-#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <atomic>
-#include <functional>
-#include <new>
+#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "dh_internal.h"
 
 // ------------------------------------------------------------------ errors
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char *fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-    return code;
-}
+#define fail dh_fail_          // (dh_host.cpp: one message slot per host thread)
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? DH_ENOMEM : DH_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-// shared with dh_biwi.hip
-int dh_fail_(int code, const char *fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-extern "C" const char *dh_last_error(void) { return g_err; }
+extern "C" const char *dh_last_error(void) { return dh_err_get_(); }
 extern "C" int dh_version(void) { return DH_VERSION; }
 
-// ------------------------------------------------------------------ forest (host side)
-struct dh_forest {
-    std::vector<int32_t> roots;
-    std::vector<dh_node> nodes;
-    std::vector<double> leaf_prob;
-    std::vector<uint32_t> off_begin, rot_begin;
-    std::vector<float> offsets;
-    std::vector<double> rotations;
-    uint32_t max_depth = 0;
-    uint16_t max_x = 0, max_y = 0;   // largest rectangle corner used by any node
-    bool uniform = false;            // every split rectangle has the same non-empty size
-    uint16_t rw = 0, rh = 0;
-};
+// ------------------------------------------------------------------ forest (host side: dh_host.cpp validates and copies)
+static int forest_create_(const dh_forest_desc *d, dh_forest **out) { return dh_forest_build_(d, out); }
 
-static inline int32_t rot_bin_host(double deg) {
-    // (deg * 120 / 360) as i32 + 60 (prediction.rs:605-613); only used to validate the forest
-    double v = deg * 120.0 / 360.0;
-    int32_t r;
-    if (v != v) r = 0;
-    else if (v >= 2147483648.0) r = INT32_MAX;
-    else if (v <= -2147483648.0) r = INT32_MIN;
-    else r = (int32_t)v;
-    return (int32_t)((uint32_t)r + 60u);
-}
-
-extern "C" int dh_forest_create(const dh_forest_desc *d, dh_forest **out) {
-    if (!d || !out) return fail(DH_EINVAL, "dh_forest_create: NULL argument");
-    *out = nullptr;
-    if (d->n_trees == 0 || !d->roots) return fail(DH_EINVAL, "forest has no trees");
-    if (d->n_leaves == 0 || !d->leaf_prob || !d->off_begin || !d->rot_begin) return fail(DH_EINVAL, "forest has no leaves");
-    if (d->n_nodes && !d->nodes) return fail(DH_EINVAL, "nodes is NULL");
-    if (d->n_nodes > 0x7fffffffu || d->n_leaves > 0x7fffffffu) return fail(DH_EINVAL, "forest too large");
-    const uint32_t NL = d->n_leaves, NN = d->n_nodes;
-    if (d->off_begin[0] != 0 || d->rot_begin[0] != 0) return fail(DH_EFOREST, "CSR arrays must start at 0");
-    for (uint32_t i = 0; i < NL; ++i)
-        if (d->off_begin[i + 1] < d->off_begin[i] || d->rot_begin[i + 1] < d->rot_begin[i])
-            return fail(DH_EFOREST, "CSR arrays not monotone at leaf %u", i);
-    const uint32_t n_off = d->off_begin[NL], n_rot = d->rot_begin[NL];
-    if ((n_off && !d->offsets) || (n_rot && !d->rotations)) return fail(DH_EINVAL, "vote arrays are NULL");
-
-    dh_forest *f = new (std::nothrow) dh_forest;
-    if (!f) return fail(DH_ENOMEM, "out of host memory");
-    try {
-        f->roots.assign(d->roots, d->roots + d->n_trees);
-        f->nodes.assign(d->nodes, d->nodes + NN);
-        f->leaf_prob.assign(d->leaf_prob, d->leaf_prob + NL);
-        f->off_begin.assign(d->off_begin, d->off_begin + NL + 1);
-        f->rot_begin.assign(d->rot_begin, d->rot_begin + NL + 1);
-        f->offsets.assign(d->offsets, d->offsets + (size_t)n_off * 3);
-        f->rotations.assign(d->rotations, d->rotations + (size_t)n_rot * 3);
-    } catch (...) {
-        delete f;
-        return fail(DH_ENOMEM, "out of host memory");
-    }
-
-    // ---- structure: every child in range, every node reached at most once (a forest of trees:
-    // guarantees each walk ends after at most max_depth steps), rectangles well-formed
-    std::vector<uint8_t> seen(NN, 0);
-    std::vector<std::pair<int32_t, uint32_t>> stack;
-    auto bad = [&](int code, const char *msg, long a) { delete f; return fail(code, msg, a); };
-    for (uint32_t t = 0; t < d->n_trees; ++t) {
-        int32_t r = f->roots[t];
-        if (r >= 0 ? (uint32_t)r >= NN : (uint32_t)(~r) >= NL) return bad(DH_EFOREST, "root of tree %ld out of range", t);
-        if (r < 0) continue;
-        stack.clear();
-        stack.push_back({r, 1u});
-        while (!stack.empty()) {
-            auto [n, depth] = stack.back();
-            stack.pop_back();
-            if (seen[n]) return bad(DH_EFOREST, "node %ld is reachable twice (cycle or shared subtree)", n);
-            seen[n] = 1;
-            f->max_depth = std::max(f->max_depth, depth);
-            const dh_node &nd = f->nodes[n];
-            for (const uint16_t *rc : {nd.r1, nd.r2}) {
-                if (rc[2] < rc[0] || rc[3] < rc[1]) return bad(DH_EFOREST, "node %ld: rectangle with negative extent", n);
-                f->max_x = std::max(f->max_x, rc[2]);
-                f->max_y = std::max(f->max_y, rc[3]);
-            }
-            if (nd.threshold != nd.threshold) return bad(DH_EFOREST, "node %ld: NaN threshold", n);
-            for (int32_t c : {nd.child_zero, nd.child_one}) {
-                if (c >= 0) {
-                    if ((uint32_t)c >= NN) return bad(DH_EFOREST, "node %ld: child out of range", n);
-                    stack.push_back({c, depth + 1});
-                } else if ((uint32_t)(~c) >= NL) {
-                    return bad(DH_EFOREST, "node %ld: leaf out of range", n);
-                }
-            }
-        }
-    }
-    for (uint32_t L = 0; L < NL; ++L)
-        if (f->off_begin[L + 1] - f->off_begin[L] >= (1u << 24) || f->rot_begin[L + 1] - f->rot_begin[L] >= (1u << 16))
-            return bad(DH_EFOREST, "leaf %ld: more than 2^24 offset or 2^16 rotation votes", L);
-    // ---- one rectangle size for the whole forest? (the in-tree trainer's geometry)
-    if (NN > 0) {
-        const dh_node &n0 = f->nodes[0];
-        f->rw = (uint16_t)(n0.r1[2] - n0.r1[0]); f->rh = (uint16_t)(n0.r1[3] - n0.r1[1]);
-        f->uniform = f->rw > 0 && f->rh > 0;
-        for (uint32_t i = 0; i < NN && f->uniform; ++i)
-            for (const uint16_t *rc : {f->nodes[i].r1, f->nodes[i].r2})
-                if (rc[2] - rc[0] != f->rw || rc[3] - rc[1] != f->rh) f->uniform = false;
-    }
-    // ---- leaves that can vote
-    for (uint32_t L = 0; L < NL; ++L) {
-        if (!(f->leaf_prob[L] > 0.0)) continue;
-        if (f->off_begin[L + 1] == f->off_begin[L]) return bad(DH_EFOREST, "leaf %ld: prob > 0 but no offsets (reference divides by zero)", L);
-        if (f->rot_begin[L + 1] == f->rot_begin[L]) return bad(DH_EFOREST, "leaf %ld: prob > 0 but no rotations (reference unwraps None)", L);
-        for (uint32_t i = f->rot_begin[L]; i < f->rot_begin[L + 1]; ++i)
-            for (int k = 0; k < 3; ++k) {
-                int32_t r = rot_bin_host(f->rotations[(size_t)i * 3 + k]);
-                if (r >= DH_ROT_GRID_PARTS) r -= DH_ROT_GRID_PARTS;
-                else if (r < 0) r += DH_ROT_GRID_PARTS;
-                if (r < 0 || r >= DH_ROT_GRID_PARTS) return bad(DH_EFOREST, "leaf %ld: rotation bin outside [0,120) after one wrap (reference indexes out of bounds)", L);
-            }
-    }
-    *out = f;
-    return DH_OK;
-}
-
-extern "C" int dh_forest_destroy(dh_forest *f) {
+static int forest_destroy_(dh_forest *f) {
     delete f;
     return DH_OK;
 }
 
-extern "C" int dh_forest_info(const dh_forest *f, uint32_t *n_trees, uint32_t *n_nodes, uint32_t *n_leaves, uint32_t *max_depth) {
+static int forest_info_(const dh_forest *f, uint32_t *n_trees, uint32_t *n_nodes, uint32_t *n_leaves, uint32_t *max_depth) {
     if (!f) return fail(DH_EINVAL, "dh_forest_info: NULL forest");
     if (n_trees) *n_trees = (uint32_t)f->roots.size();
     if (n_nodes) *n_nodes = (uint32_t)f->nodes.size();
@@ -180,34 +45,10 @@ extern "C" int dh_forest_info(const dh_forest *f, uint32_t *n_trees, uint32_t *n
     return DH_OK;
 }
 
-// ------------------------------------------------------------------ geometry
-struct Geom {
-    int w = 0, h = 0, nx = 0, ny = 0, npatch = 0;
-    int px = 0, py = 0, tiles_x = 0, tiles_y = 0, ss_max = 0, ss_row = 0, swz_log2 = 0, swz_q = 0;
-    bool uniform = false;       // uniform-rectangle path: k_boxsum feeds k_traverse<true>
-    int top_levels = 0;         // uniform path with the walk table: tree levels walked from the LDS copy of the tree tops
-    int flag_words = 0;                // per frame: u32 words holding one flag byte per tile (uniform path)
-    int win_cap = 0;                   // slots of a frame's window list: tiles * px * py
-    int box_plane = 0, box_rows = 0, box_ow = 0, box_oh = 0, box_parts = 0, box_bands = 0;
-    size_t lds = 0;
-};
-
-static int patch_grid(const dh_params &p, int w, int h, int *nx, int *ny) {
-    if (p.stepwidth == 0 || p.subimage_width == 0 || p.subimage_height == 0) return fail(DH_EINVAL, "zero stepwidth / patch size");
-    if (w <= 0 || h <= 0) return fail(DH_EINVAL, "non-positive frame size");
-    // the reference computes `h - right_h` in u32 and panics in SubImage::new when the frame is
-    // smaller than the patch (prediction.rs:546-548, :565)
-    if ((uint32_t)w < p.subimage_width || (uint32_t)h < p.subimage_height) return fail(DH_ESIZE, "frame %dx%d smaller than the %ux%u patch", w, h, p.subimage_width, p.subimage_height);
-    uint32_t lw = p.subimage_width / 2, rw = p.subimage_width - lw, lh = p.subimage_height / 2, rh = p.subimage_height - lh;
-    uint32_t xe = (uint32_t)w - rw, ye = (uint32_t)h - rh;
-    *nx = xe > lw ? (int)((xe - lw + p.stepwidth - 1) / p.stepwidth) : 0;
-    *ny = ye > lh ? (int)((ye - lh + p.stepwidth - 1) / p.stepwidth) : 0;
-    return DH_OK;
-}
-
-extern "C" int dh_patch_grid(const dh_params *p, int w, int h, int *nx, int *ny) {
+// ------------------------------------------------------------------ geometry (dh_host.cpp)
+static int patch_grid_(const dh_params *p, int w, int h, int *nx, int *ny) {
     if (!p || !nx || !ny) return fail(DH_EINVAL, "dh_patch_grid: NULL argument");
-    return patch_grid(*p, w, h, nx, ny);
+    return dh_patch_grid_(*p, w, h, nx, ny);
 }
 
 // Entry points run on the predictor's device and leave the caller's current device as they found it.
@@ -224,71 +65,7 @@ struct DeviceGuard {
 
 // ------------------------------------------------------------------ predictor
 #define DH_MAX_CHUNKS 8
-#define DH_STAGE_EVENTS 16       // upload chunks in flight per slice
-// Knobs::leaf_hist_max = 16384: per-frame leaf histogram for the rotation gather (64 KB per frame at most); larger forests
-                                 // rarely hit a leaf twice per frame and walk the hit records instead (measured: 35 k leaves is a loss)
 #define DH_MIN_CHUNK_FRAMES 16
-
-// Diagnostic switches.  The environment is read ONCE, by dh_predictor_create; none of these changes
-// results (the GPU suite runs under each).  The switches that truncate kernels for per-phase
-// profiling ("results invalid") exist only in builds with -DDH_PROFILING_KNOBS (tools/), never in the
-// product library.
-struct Knobs {
-    bool force_general = false;       // DH_FORCE_GENERAL: mixed-rectangle path for any forest
-    bool no_leaf_hist = false;        // DH_NO_LEAF_HIST
-    bool box_no_ring = false;         // DH_BOX_NO_RING
-    uint32_t leaf_hist_max = 16384;   // DH_LEAF_HIST_MAX
-    int lds_budget_kb = 0;            // DH_LDS_BUDGET_KB
-    int tile_x = 0, tile_y = 0;       // DH_TILE=px,py
-    int box_band = 64;                // DH_BOX_BAND
-    int max_resident = 512;           // DH_MAX_RESIDENT_FRAMES
-    int chunks = 0;                   // DH_CHUNKS: forked sub-batches per call; 0 = automatic (two once a call brings >= 512 frames)
-    bool box_dense = false;           // DH_BOX_DENSE: k_boxsum stores every cell (no skipping of zero over zero)
-    bool no_region = false;           // DH_NO_REGION: k_cluster always gathers its first region itself
-    int region_min_hits = 0;          // DH_REGION_MIN_HITS: hit records in a frame from which k_region pre-gathers its first regions (small batches);
-                                      //   0 = automatic: 8192 for forests without leaf histogram (their rotation gather costs ~9 ns a record), 65536 with
-    int top_levels = -1;              // DH_TOP_LEVELS: tree levels walked from the LDS copy of the tree tops (-1 = auto, 0 = none)
-    bool no_tile_list = false;        // DH_NO_TILE_LIST: k_traverse launches a workgroup per tile position, empty ones included, in place
-    bool vote_exact = false;          // DH_VOTE_EXACT: k_vote takes the two IEEE divisions for every vote (no approximate-quotient cell test)
-    bool no_absorb = false;           // DH_NO_ABSORB: uniform path walks the guarded node table even when no node is ambiguous
-    bool no_general_int = false;      // DH_NO_GENERAL_INT: general path with the f64 divisions on every visit
-    int stage_chunk = 64;             // DH_STAGE_CHUNK: frames per upload chunk of the host entry points (copy of chunk k + 1 overlaps the kernels of chunk k)
-    int host_threads = 8;             // DH_HOST_THREADS: host threads that validate / pack run-length coded payloads
-#ifdef DH_PROFILING_KNOBS
-    int trav_stop = 0, emit_stop = 0, vote_stop = 0, cl_stop = 0;
-    bool trav_stamps = false;
-#endif
-};
-
-static Knobs read_knobs() {
-    Knobs k;
-    auto geti = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
-    k.force_general = getenv("DH_FORCE_GENERAL") != nullptr;
-    k.no_leaf_hist = getenv("DH_NO_LEAF_HIST") != nullptr;
-    k.box_no_ring = getenv("DH_BOX_NO_RING") != nullptr;
-    k.leaf_hist_max = (uint32_t)std::max(0, geti("DH_LEAF_HIST_MAX", 16384));
-    k.lds_budget_kb = std::max(0, geti("DH_LDS_BUDGET_KB", 0));
-    if (const char *e = getenv("DH_TILE")) sscanf(e, "%d,%d", &k.tile_x, &k.tile_y);
-    k.box_band = std::max(1, geti("DH_BOX_BAND", 64));
-    k.max_resident = std::max(1, geti("DH_MAX_RESIDENT_FRAMES", 512));
-    k.chunks = std::max(0, std::min(8, geti("DH_CHUNKS", 0)));
-    k.box_dense = getenv("DH_BOX_DENSE") != nullptr;
-    k.no_region = getenv("DH_NO_REGION") != nullptr;
-    k.region_min_hits = std::max(0, geti("DH_REGION_MIN_HITS", 0));
-    k.no_general_int = getenv("DH_NO_GENERAL_INT") != nullptr;
-    k.no_absorb = getenv("DH_NO_ABSORB") != nullptr;
-    k.vote_exact = getenv("DH_VOTE_EXACT") != nullptr;
-    k.no_tile_list = getenv("DH_NO_TILE_LIST") != nullptr;
-    if (const char *e = getenv("DH_TOP_LEVELS")) k.top_levels = std::max(0, std::min(8, atoi(e)));
-    k.stage_chunk = std::max(1, geti("DH_STAGE_CHUNK", 64));
-    k.host_threads = std::max(1, std::min(64, geti("DH_HOST_THREADS", (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())))));
-#ifdef DH_PROFILING_KNOBS
-    k.trav_stop = geti("DH_TRAV_STOP", 0); k.emit_stop = geti("DH_EMIT_STOP", 0);
-    k.vote_stop = geti("DH_VOTE_STOP", 0); k.cl_stop = geti("DH_CL_STOP", 0);
-    k.trav_stamps = getenv("DH_TRAV_STAMPS") != nullptr;
-#endif
-    return k;
-}
 
 struct dh_predictor {
     int device = 0;
@@ -316,6 +93,7 @@ struct dh_predictor {
     hipEvent_t ev_stage[DH_STAGE_EVENTS] = {};   // chunk k uploaded (recorded on an upload stream, waited for on own_stream)
     hipEvent_t ev_slice = nullptr;        // the kernels that read the staging buffers are done (recorded on own_stream)
     // run-length coded input (dh_predict_batch_rle): pinned staging + device copies of payload blob and run table
+    uint8_t *pin_small = nullptr; size_t pin_small_cap = 0;   // page-locked staging of a slice's small host arrays: poses out, guesses in (small_stage)
     uint8_t *pin_blob = nullptr;  size_t pin_blob_cap = 0;
     uint2 *pin_runs = nullptr;    size_t pin_runs_cap = 0;
     uint32_t *pin_begin = nullptr; size_t pin_begin_cap = 0;
@@ -404,27 +182,9 @@ static int upload(dh_predictor *p, const T **out, const std::vector<T> &v) {
     return DH_OK;
 }
 
-// Mat3<f32>::inv = adjugate / det, element-wise (meancov_estimation.rs:339-352); f32, no FMA
-// (this translation unit is compiled with -ffp-contract=off).
-static void mat3_inv_f32(const float m[9], float o[9]) {
-    const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
-    const float det = a * (e * i - f * h) - d * (b * i - c * h) + g * (b * f - c * e);   // :340-342
-    o[0] = (e * i - f * h) / det; o[1] = (c * h - b * i) / det; o[2] = (b * f - c * e) / det;   // :348-350
-    o[3] = (f * g - d * i) / det; o[4] = (a * i - c * g) / det; o[5] = (c * d - a * f) / det;
-    o[6] = (d * h - e * g) / det; o[7] = (b * g - a * h) / det; o[8] = (a * e - b * d) / det;
-}
-
-// FullArray3D::build_kernel(20, sigma) (meanshift.rs:228-252), stored in summation order
-// (dx*20+dy)*20+dz; the reference indexes kernel[(x+10, y+10, z+10)] = data[z*400 + y*20 + x].
 static int build_kernel_table(dh_predictor *p) {
-    std::vector<float> k(DH_GRID3);
-    for (int x = 0; x < DH_GRID; ++x)
-        for (int y = 0; y < DH_GRID; ++y)
-            for (int z = 0; z < DH_GRID; ++z) {
-                int dx = x - 10, dy = y - 10, dz = z - 10;
-                int norm = dx * dx + dy * dy + dz * dz;
-                k[(x * DH_GRID + y) * DH_GRID + z] = expf(-1.0f * (float)norm / (2.0f * p->params.gaussian_sigma));
-            }
+    std::vector<float> k;
+    dh_build_kernel_table_(p->params.gaussian_sigma, k);    // get_or_build_kernel caches it per sigma (prediction.rs:310-317)
     HIP_TRY(hipMemcpy(p->kern_ord, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
     return DH_OK;
 }
@@ -452,7 +212,7 @@ static void free_workspace(dh_predictor *p) {
     p->geom = Geom();
 }
 
-extern "C" int dh_predictor_destroy(dh_predictor *p) {
+static int predictor_destroy_(dh_predictor *p) {
     if (!p) return DH_OK;
     (void)hipSetDevice(p->device);
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
@@ -469,6 +229,7 @@ extern "C" int dh_predictor_destroy(dh_predictor *p) {
     if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
     for (auto &e : p->ev_stage) if (e) (void)hipEventDestroy(e);
     if (p->ev_slice) (void)hipEventDestroy(p->ev_slice);
+    if (p->pin_small) (void)hipHostFree(p->pin_small);
     if (p->pin_blob) (void)hipHostFree(p->pin_blob);
     if (p->pin_runs) (void)hipHostFree(p->pin_runs);
     if (p->pin_begin) (void)hipHostFree(p->pin_begin);
@@ -480,7 +241,9 @@ extern "C" int dh_predictor_destroy(dh_predictor *p) {
     return DH_OK;
 }
 
-extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int device, dh_predictor **out) {
+static int predictor_build(dh_predictor *p, const dh_forest *f, const dh_params *prm, int device);
+
+static int predictor_create_(const dh_forest *f, const dh_params *prm, int device, dh_predictor **out) {
     if (!f || !prm || !out) return fail(DH_EINVAL, "dh_predictor_create: NULL argument");
     *out = nullptr;
     if (prm->stepwidth == 0 || prm->subimage_width == 0 || prm->subimage_height == 0) return fail(DH_EINVAL, "zero stepwidth / patch size");
@@ -497,9 +260,22 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
 
     dh_predictor *p = new (std::nothrow) dh_predictor;
     if (!p) return fail(DH_ENOMEM, "out of host memory");
+    // (a host allocation failing half-way -- the packed vote arrays, the general-path nodes -- must not leak the device side)
+    int rc = dh_guard_("dh_predictor_create", [&]() -> int { return predictor_build(p, f, prm, device); });
+    if (rc != DH_OK) {
+        const std::string keep = dh_err_get_();
+        predictor_destroy_(p);
+        dh_err_set_(keep.c_str());
+        return rc;
+    }
+    *out = p;
+    return DH_OK;
+}
+
+static int predictor_build(dh_predictor *p, const dh_forest *f, const dh_params *prm, int device) {
     p->device = device;
     p->params = *prm;
-    p->knobs = read_knobs();   // the only place the environment is read
+    p->knobs = dh_read_knobs_();   // the only place the environment is read
     p->n_trees = (uint32_t)f->roots.size(); p->n_nodes = (uint32_t)f->nodes.size(); p->n_leaves = (uint32_t)f->leaf_prob.size();
     p->n_off = f->off_begin.back(); p->n_rot = f->rot_begin.back(); p->max_depth = f->max_depth;
     p->f_uniform = f->uniform; p->f_rw = f->rw; p->f_rh = f->rh;
@@ -516,12 +292,11 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
     if (rc == DH_OK) {
         // the offset votes once more as (x, y, z, 0) records, every leaf's run on a 64-byte boundary: the kernels
         // that walk a leaf's votes (k_vote, k_cluster) then touch whole cache lines with one 16-byte load per lane
-        std::vector<uint32_t> b4(p->n_leaves + 1, 0);
-        for (uint32_t L = 0; L < p->n_leaves; ++L) b4[L + 1] = b4[L] + ((f->off_begin[L + 1] - f->off_begin[L] + 3u) & ~3u);
-        std::vector<float4> o4((size_t)b4[p->n_leaves] + 4, make_float4(0.f, 0.f, 0.f, 0.f));
-        for (uint32_t L = 0; L < p->n_leaves; ++L)
-            for (uint32_t k = f->off_begin[L]; k < f->off_begin[L + 1]; ++k)
-                o4[b4[L] + (k - f->off_begin[L])] = make_float4(f->offsets[(size_t)k * 3], f->offsets[(size_t)k * 3 + 1], f->offsets[(size_t)k * 3 + 2], 0.f);
+        std::vector<uint32_t> b4;
+        std::vector<float> o4f;
+        dh_pack_off4_(*f, b4, o4f);
+        std::vector<float4> o4(o4f.size() / 4);
+        memcpy(o4.data(), o4f.data(), o4f.size() * sizeof(float));
         STEP(upload(p, &d.off4, o4));
         STEP(upload(p, &d.off4_begin, b4));
     }
@@ -545,31 +320,9 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
         STEP(dev_alloc(p, &p->amb_list, DH_AMB_CAP, true));
     }
     if (rc == DH_OK && prm->subimage_width <= 255 && prm->subimage_height <= 255 && p->n_nodes > 0) {
-        // Integer split bounds of the general path (NodeG, see k_traverse): with C_i = max(c_i, 1), delta = (s1 C2 - s2 C1) / (C1 C2)
-        // and |d - delta| < 2^-35, so D = s1 C2 - s2 C1 <= floor((thr - 2^-34) C1 C2 - pad) decides Zero and
-        // D >= ceil((thr + 2^-34) C1 C2 + pad) decides One; pad covers the rounding of these f64 products (C1 C2 < 2^32,
-        // |thr| <= 65535: the products are below 2^48, their rounding error below 2^-4) with room to spare.
-        std::vector<NodeG> ng(p->n_nodes);
-        for (uint32_t i = 0; i < p->n_nodes; ++i) {
-            const dh_node &nd = f->nodes[i];
-            NodeG o{};
-            for (int k = 0; k < 4; ++k) { o.r1[k] = (uint8_t)nd.r1[k]; o.r2[k] = (uint8_t)nd.r2[k]; }
-            const uint32_t c1 = (uint32_t)(nd.r1[2] - nd.r1[0]) * (uint32_t)(nd.r1[3] - nd.r1[1]);
-            const uint32_t c2 = (uint32_t)(nd.r2[2] - nd.r2[0]) * (uint32_t)(nd.r2[3] - nd.r2[1]);
-            const uint32_t C1 = std::max(c1, 1u), C2 = std::max(c2, 1u);            // <= 255 * 255
-            o.cc = C1 | (C2 << 16);
-            o.child_zero = nd.child_zero; o.child_one = nd.child_one;
-            const double thr = nd.threshold, cc = (double)C1 * (double)C2;
-            if (thr >= 65535.0) { o.ilo = INT64_MAX - 16; o.amb = 0; }              // mean difference <= 65535: never greater
-            else if (thr < -65535.0) { o.ilo = INT64_MIN; o.amb = 0; }             // >= -65535: always greater
-            else {
-                const double m = 5.820766091346741e-11;                             // 2^-34
-                const double lo = floor((thr - m) * cc - 1.0), hi = ceil((thr + m) * cc + 1.0);
-                o.ilo = (int64_t)lo;
-                o.amb = (uint32_t)std::min<int64_t>((int64_t)hi - (int64_t)lo - 1, 0xffffffffll);
-            }
-            ng[i] = o;
-        }
+        // Integer split bounds of the general path (NodeG: dh_host.h, k_traverse.hip)
+        std::vector<NodeG> ng;
+        dh_build_nodes_g_(*f, ng);
         NodeG *dg = nullptr;
         STEP(dev_alloc(p, &dg, p->n_nodes, true));
         if (rc == DH_OK && hipMemcpy(dg, ng.data(), ng.size() * sizeof(NodeG), hipMemcpyHostToDevice) != hipSuccess) rc = fail(DH_EHIP, "hipMemcpy(NodeG)");
@@ -580,7 +333,7 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
         if (rc == DH_OK && e != hipSuccess) rc = fail(DH_EHIP, "%s: %s", what, hipGetErrorString(e));
     };
     if (rc == DH_OK) hipstep(hipMemset(p->zeros, 0, 64), "hipMemset");
-    if (rc == DH_OK) hipstep(dh_kernels_init(), "hipFuncSetAttribute");
+    if (rc == DH_OK) hipstep(dh_kernels_init(device), "hipFuncSetAttribute");
     if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking), "hipStreamCreate");
     if (rc == DH_OK) hipstep(dh_launch_leaf_prepare(d, p->own_stream), "k_leaf_prepare launch");
     if (rc == DH_OK) hipstep(hipStreamSynchronize(p->own_stream), "k_leaf_prepare");
@@ -621,18 +374,10 @@ extern "C" int dh_predictor_create(const dh_forest *f, const dh_params *prm, int
         if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->aux_stream[i], hipStreamNonBlocking), "hipStreamCreate");
         if (rc == DH_OK) hipstep(hipEventCreateWithFlags(&p->ev_join[i], hipEventDisableTiming), "hipEventCreate");
     }
-    if (rc != DH_OK) {
-        char keep[sizeof g_err];
-        memcpy(keep, g_err, sizeof keep);
-        dh_predictor_destroy(p);
-        memcpy(g_err, keep, sizeof keep);
-        return rc;
-    }
-    *out = p;
-    return DH_OK;
+    return rc;
 }
 
-extern "C" int dh_predictor_update_sigma(dh_predictor *p, float val) {
+static int predictor_update_sigma_(dh_predictor *p, float val) {
     if (!p) return fail(DH_EINVAL, "NULL predictor");
     if (val == p->params.gaussian_sigma || val <= 0.0f || val != val) return DH_OK;   // prediction.rs:321-323
     HIP_TRY(hipSetDevice(p->device));
@@ -640,100 +385,24 @@ extern "C" int dh_predictor_update_sigma(dh_predictor *p, float val) {
     p->params.gaussian_sigma = val;
     return build_kernel_table(p);
 }
-extern "C" int dh_predictor_sigma(const dh_predictor *p, float *out) {
+static int predictor_sigma_(const dh_predictor *p, float *out) {
     if (!p || !out) return fail(DH_EINVAL, "NULL argument");
     *out = p->params.gaussian_sigma;
     return DH_OK;
 }
 
-// Image columns one k_boxsum wave spans (dh_kernels.hip) and the largest rectangle edge it serves.
-static const int kBoxSpan = 256, kBoxMaxRect = 96;
-
-// Tile of PX x PY window positions per workgroup: as many positions as fit the LDS budget
-// (SAT footprint or box-sum region + leaf ids), at most 1024 (one thread per position in the tail).
 static int choose_tile(const dh_predictor *p, Geom &g) {
-    const int step = (int)p->params.stepwidth, sw = (int)p->params.subimage_width, sh = (int)p->params.subimage_height;
-    const int rw = g.uniform ? p->f_rw : 0, rh = g.uniform ? p->f_rh : 0;
-    size_t budget = 79 * 1024;   // two 1024-thread workgroups per CU (160 KB LDS)
-    if (p->knobs.lds_budget_kb > 0) budget = (size_t)p->knobs.lds_budget_kb * 1024;
-    budget = std::min<size_t>(budget, 158 * 1024);
-    const int fx = p->knobs.tile_x, fy = p->knobs.tile_y;
-    // Tree levels walked from LDS (walk_absorb; 12 bytes per heap slot and tree).  LDS given to the tree tops is taken from the
-    // tile, and every tile copies them: 4 KB measured best on the bench workload (10 trees, stride 4: 5 levels 0.175 ms,
-    // 6 levels 0.188) and for 20 trees at stride 4 (4 levels 0.157, 5 levels 0.166, 7 levels 0.191).  More trees mean more walks
-    // per window, and a smaller stride means more windows per byte of region -- both make a level saved worth more LDS:
-    // config 3 (50 trees, stride 2) 6 levels 0.284 ms, 5 levels 0.313, 4 levels 0.343, 2 levels 0.365; config 5 (stride 1) 8 levels.
-    // Hence 200 bytes per tree, scaled by (4 / stride)^2, between 4 and 40 KB; then whatever fits beside the tile for nothing.
-    g.top_levels = 0;
-    if (g.uniform && p->absorb_ok) {
-        if (p->top_levels >= 0) g.top_levels = p->top_levels;
-        else {
-            const double want = 200.0 * p->n_trees * 16.0 / ((double)step * step);
-            const size_t top_budget = (size_t)std::min(40.0 * 1024, std::max(4.0 * 1024, want));
-            while (g.top_levels < 8 && (size_t)p->n_trees * (2u << g.top_levels) * 12 <= top_budget) ++g.top_levels;
-        }
-        while (g.top_levels > 0 && (size_t)p->n_trees * (1u << g.top_levels) * 12 > 48 * 1024) --g.top_levels;
-    }
-    const int top_words = g.uniform && p->absorb_ok ? (int)p->n_trees * (1 << g.top_levels) * 3 : 0;
-    long best = -1;
-    for (int py = 1; py <= std::min(g.ny, 64); ++py)
-        for (int px = 1; px <= std::min(g.nx, 64); ++px) {
-            if (px * py > 1024) continue;
-            if (fx > 0 && fy > 0 && (px != std::min(fx, g.nx) || py != std::min(fy, g.ny))) continue;
-            // uniform path: tiles start on 16-byte boundaries of the box image's planes (direct-to-LDS copy)
-            if (rw > 0 && (px & 3) != 0 && px < g.nx && !(fx > 0)) continue;
-            // uniform path: the packed rectangle offsets of a compact node are 14-bit
-            if (rw > 0 && (long)(sh - rh + 1) * dh_traverse_row_stride(px, step, sw, rw) >= 16384) continue;
-            size_t lds = dh_traverse_lds_bytes(px, py, step, sw, sh, top_words, rw, rh);
-            if (lds > budget && !(fx > 0 && lds <= 158 * 1024)) continue;
-            long score = (long)px * py * 1000 - labs((long)px - py);
-            if (score > best) { best = score; g.px = px; g.py = py; g.lds = lds; }
-        }
-    if (best < 0) {
-        // a single position must always fit
-        if (rw > 0 && (long)(sh - rh + 1) * dh_traverse_row_stride(1, step, sw, rw) >= 16384) return 1;   // caller retries on the general path
-        g.px = g.py = 1;
-        g.lds = dh_traverse_lds_bytes(1, 1, step, sw, sh, top_words, rw, rh);
-        if (g.lds > 158 * 1024) return rw > 0 ? 1 : fail(DH_ESIZE, "patch %dx%d with %u trees does not fit LDS", sw, sh, p->n_trees);
-    }
-    // a tile capped by its 1024 threads (small strides) or by the frame leaves LDS unused: more tree levels fit for nothing
-    if (g.uniform && p->absorb_ok && p->top_levels < 0)
-        while (g.top_levels < 8 && g.lds + (size_t)p->n_trees * (1u << g.top_levels) * 12 <= budget) {
-            g.lds += (size_t)p->n_trees * (1u << g.top_levels) * 12;      // (doubling the table adds its current size)
-            ++g.top_levels;
-        }
-    g.tiles_x = (g.nx + g.px - 1) / g.px;
-    g.tiles_y = (g.ny + g.py - 1) / g.py;
-    if ((long)g.tiles_x * g.tiles_y > 65535) return fail(DH_ESIZE, "frame %dx%d needs %ld tiles per frame (limit 65535)", g.w, g.h, (long)g.tiles_x * g.tiles_y);
-    g.win_cap = g.tiles_x * g.tiles_y * g.px * g.py;
-    g.flag_words = (g.tiles_x * g.tiles_y + 3) / 4;
-    g.ss_row = dh_traverse_row_stride(g.px, step, sw, rw);
-    if (rw > 0) dh_traverse_swizzle(g.px, step, sw, rw, &g.swz_log2, &g.swz_q, &g.ss_row);
-    g.ss_max = g.ss_row * ((g.py - 1) * step + sh + (rw > 0 ? 1 - rh : 1));
-    if (rw > 0) {
-        g.box_rows = g.h - rh + 1;
-        // a row of the image = m planes (same de-interleave as the LDS region) of box_plane words;
-        // the slack lets a tile read whole 16-byte groups past its last column
-        const int m = 1 << g.swz_log2;
-        g.box_plane = ((g.w - rw + 1 + m - 1) / m + 4 + 3) & ~3;
-        // one wave yields up to 256 - rw columns (a multiple of 4) of a band of rows; bands are sized so
-        // that a batch of a few hundred frames fills the chip once (about 24 waves per frame at VGA)
-        const int bw = g.w - rw + 1, ow_max = (kBoxSpan - rw) & ~3;
-        g.box_parts = (bw + ow_max - 1) / ow_max;
-        g.box_ow = std::min(ow_max, ((bw + g.box_parts - 1) / g.box_parts + 3) & ~3);
-        const int band = p->knobs.box_band;
-        g.box_bands = (g.box_rows + band - 1) / band;
-        g.box_oh = ((g.box_rows + g.box_bands - 1) / g.box_bands + 31) & ~31;     // whole 32-row blocks per band (BoxArgs::blk_mask)
-        g.box_bands = (g.box_rows + g.box_oh - 1) / g.box_oh;
-    }
-    return DH_OK;
+    TileQuery q;
+    q.params = p->params; q.f_rw = p->f_rw; q.f_rh = p->f_rh; q.n_trees = p->n_trees; q.absorb_ok = p->absorb_ok; q.top_levels = p->top_levels;
+    q.lds_budget_kb = p->knobs.lds_budget_kb; q.tile_x = p->knobs.tile_x; q.tile_y = p->knobs.tile_y; q.box_band = p->knobs.box_band;
+    return dh_choose_tile_(q, g);
 }
 
 static int reserve(dh_predictor *p, int n, int w, int h) {
     if (n <= 0) return fail(DH_EINVAL, "batch size must be positive");
     Geom g;
     g.w = w; g.h = h;
-    int rc = patch_grid(p->params, w, h, &g.nx, &g.ny);
+    int rc = dh_patch_grid_(p->params, w, h, &g.nx, &g.ny);
     if (rc) return rc;
     g.npatch = g.nx * g.ny;
     bool same_geom = p->geom.w == w && p->geom.h == h;
@@ -821,7 +490,7 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     return DH_OK;
 }
 
-extern "C" int dh_predictor_reserve(dh_predictor *p, int n, int w, int h) {
+static int predictor_reserve_(dh_predictor *p, int n, int w, int h) {
     if (!p) return fail(DH_EINVAL, "NULL predictor");
     return reserve(p, n, w, h);
 }
@@ -987,7 +656,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
 // stream, reusing the workspace.
 static int max_resident_frames(const dh_predictor *p) { return p->knobs.max_resident; }
 
-extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+static int predict_batch_device_(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                                        const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
                                        dh_pose *out, void *stream_) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_batch_device: NULL argument");
@@ -1000,7 +669,7 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream_;
     float kinv[9];
-    mat3_inv_f32(K, kinv);   // cached in a RefCell by the reference (types.rs:436-441)
+    dh_mat3_inv_f32_(K, kinv);   // cached in a RefCell by the reference (types.rs:436-441)
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
         // (inside a captured graph the zero-fill is a kernel node: see k_zero)
@@ -1044,10 +713,78 @@ extern "C" int dh_predict_batch_device(dh_predictor *p, const uint16_t *frames, 
 static int stage_frames(dh_predictor *p, const uint16_t *frames, int n, int w, int h);
 static int ensure_frame_staging(dh_predictor *p, size_t fbytes);
 
+template <typename T>
+static int grow_pinned(T **buf, size_t *cap, size_t need) {
+    if (need <= *cap) return DH_OK;
+    if (*buf) (void)hipHostFree(*buf);
+    *buf = nullptr; *cap = 0;
+    const size_t want = need + need / 4 + 4096;
+    void *q = nullptr;
+    hipError_t e = hipHostMalloc(&q, want * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(DH_ENOMEM, "hipHostMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+    *buf = (T *)q; *cap = want;
+    return DH_OK;
+}
+template <typename T>
+static int grow_device(T **buf, size_t *cap, size_t need) {
+    if (need <= *cap) return DH_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *cap = 0;
+    const size_t want = need + need / 4 + 4096;
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, want * sizeof(T));
+    if (e != hipSuccess) return fail(DH_ENOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+    *buf = (T *)q; *cap = want;
+    return DH_OK;
+}
+
+// The small host arrays of a slice (poses out; guesses and their mask in) cross PCIe through the predictor's OWN page-locked
+// staging block: the caller's arrays are ordinary pageable memory a few hundred bytes long, typically sharing their pages
+// with other allocations of other host threads, and handing such ranges to the runtime's pageable-copy path (pin the pages,
+// DMA, unpin -- per copy, beside other threads doing the same to neighbouring bytes) is both slower than a pinned copy and
+// the one place where concurrent predictors met inside the runtime.  Layout for m frames: poses | rot guesses | mid guesses | mask.
+struct SmallStage {
+    dh_pose *poses; double *rot; float *midp; uint8_t *mask;
+};
+static int small_stage(dh_predictor *p, int m, SmallStage *st) {
+    const size_t need = (size_t)m * (sizeof(dh_pose) + 3 * sizeof(double) + 3 * sizeof(float) + 1) + 64;
+    int rc = grow_pinned(&p->pin_small, &p->pin_small_cap, need);      // (only between slices: both streams are idle)
+    if (rc) return rc;
+    st->poses = (dh_pose *)p->pin_small;
+    st->rot = (double *)(st->poses + m);
+    st->midp = (float *)(st->rot + (size_t)m * 3);
+    st->mask = (uint8_t *)(st->midp + (size_t)m * 3);
+    return DH_OK;
+}
+// guesses of frames [f0, f0 + m) -> staging -> the workspace's device arrays, on stream s
+static int upload_guesses(dh_predictor *p, const SmallStage &st, int f0, int m, const float *midp_guess, const double *rot_guess,
+                          const uint8_t *guess_mask, hipStream_t s) {
+    if (midp_guess) {
+        memcpy(st.midp, midp_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(float));
+        HIP_TRY(hipMemcpyAsync(p->ws_midp, st.midp, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    if (rot_guess) {
+        memcpy(st.rot, rot_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(double));
+        HIP_TRY(hipMemcpyAsync(p->ws_rot, st.rot, (size_t)m * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    if (guess_mask) {
+        memcpy(st.mask, guess_mask + f0, (size_t)m);
+        HIP_TRY(hipMemcpyAsync(p->ws_mask, st.mask, (size_t)m, hipMemcpyHostToDevice, s));
+    }
+    return DH_OK;
+}
+// poses of the slice: device -> staging on s, wait, -> the caller's array
+static int download_poses(dh_predictor *p, const SmallStage &st, int m, dh_pose *out, hipStream_t s) {
+    HIP_TRY(hipMemcpyAsync(st.poses, p->ws_poses, (size_t)m * sizeof(dh_pose), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    memcpy(out, st.poses, (size_t)m * sizeof(dh_pose));
+    return DH_OK;
+}
+
 // Host entry point.  The frames cross PCIe in chunks on copy_stream while the kernels of the previous chunk run on
 // own_stream (the path is PCIe-bound: 614 KB per frame in, 40 bytes out), so a batch takes about its upload time plus
 // the kernels of the last chunk.  The poses of a slice come back in one copy.
-extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+static int predict_batch_(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                                 const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_batch: NULL argument");
     if (n == 0) return DH_OK;
@@ -1062,23 +799,13 @@ extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, 
         if (rc) return rc;
         rc = ensure_frame_staging(p, (size_t)m * fpx * sizeof(uint16_t));
         if (rc) return rc;
-        if (midp_guess) HIP_TRY(hipMemcpyAsync(p->ws_midp, midp_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, s));
-        if (rot_guess) HIP_TRY(hipMemcpyAsync(p->ws_rot, rot_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-        if (guess_mask) HIP_TRY(hipMemcpyAsync(p->ws_mask, guess_mask + f0, (size_t)m, hipMemcpyHostToDevice, s));
+        SmallStage st;
+        rc = small_stage(p, m, &st);
+        if (rc == DH_OK) rc = upload_guesses(p, st, f0, m, midp_guess, rot_guess, guess_mask, s);
+        if (rc) return rc;
         // the parity taps describe ONE device batch: with them on, the slice is a single chunk
-        int chunk = p->debug ? m : std::min(m, p->knobs.stage_chunk);
-        chunk = std::max(chunk, (m + DH_STAGE_EVENTS / 2 - 1) / (DH_STAGE_EVENTS / 2));
-        // chunk sizes taper towards the end of the slice (each at most half of what is left, at least 16 frames): the
-        // kernels of the last chunk are the only ones no upload hides
-        int cstart[DH_STAGE_EVENTS + 1], nchunks = 0;
-        for (int c0 = 0; c0 < m && nchunks < DH_STAGE_EVENTS;) {
-            cstart[nchunks++] = c0;
-            const int left = m - c0;
-            int c = std::min(chunk, std::max(16, (left + 1) / 2));
-            if (nchunks == DH_STAGE_EVENTS || left - c < 8) c = left;
-            c0 += c;
-        }
-        cstart[nchunks] = m;
+        int cstart[DH_STAGE_EVENTS + 1];
+        const int nchunks = dh_chunk_plan_(m, p->knobs.stage_chunk, p->debug, cstart);
         auto predict_chunk = [&](int c0, int cm) {
             return dh_predict_batch_device(p, p->ws_frames + (size_t)c0 * fpx, cm, w, h, K, midp_guess ? p->ws_midp + (size_t)c0 * 3 : nullptr,
                                            rot_guess ? p->ws_rot + (size_t)c0 * 3 : nullptr, guess_mask ? p->ws_mask + c0 : nullptr, p->ws_poses + c0, s);
@@ -1106,134 +833,42 @@ extern "C" int dh_predict_batch(dh_predictor *p, const uint16_t *frames, int n, 
             }
         }
         HIP_TRY(hipEventRecord(p->ev_slice, s));
-        HIP_TRY(hipMemcpyAsync(out + f0, p->ws_poses, (size_t)m * sizeof(dh_pose), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        rc = download_poses(p, st, m, out + f0, s);
+        if (rc) return rc;
     }
     return DH_OK;
 }
 
 // Page-locked host memory for frame buffers: uploads from it are asynchronous DMA at PCIe speed.
-extern "C" int dh_host_alloc(size_t bytes, void **out) {
+static int host_alloc_(size_t bytes, void **out) {
     if (!out) return fail(DH_EINVAL, "dh_host_alloc: NULL argument");
     *out = nullptr;
     hipError_t e = hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault);
     if (e != hipSuccess) { *out = nullptr; return fail(DH_ENOMEM, "hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
     return DH_OK;
 }
-extern "C" int dh_host_free(void *ptr) {
+static int host_free_(void *ptr) {
     if (ptr && hipHostFree(ptr) != hipSuccess) return fail(DH_EHIP, "hipHostFree");
     return DH_OK;
 }
 
 // ------------------------------------------------------------------ run-length coded input (BIWI `.bin`, biwi.rs:81-103)
-static void parallel_for(int n, int threads, const std::function<void(int)> &fn) {
-    threads = std::max(1, std::min(threads, n));
-    if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-    std::atomic<int> next{0};
-    auto body = [&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); };
-    std::vector<std::thread> pool;
-    pool.reserve(threads - 1);
-    try { for (int t = 1; t < threads; ++t) pool.emplace_back(body); } catch (...) { /* fewer workers: the caller's thread finishes the rest */ }
-    body();
-    for (auto &t : pool) t.join();
-}
-
-static inline uint32_t rd32(const uint8_t *q) { uint32_t v; memcpy(&v, q, 4); return v; }   // little-endian host (x86-64)
-
-// One pass over a payload's run headers with the checks of dh_biwi_decode_depth (where the reference returns an
-// io::Error or panics, biwi.rs:83-98).  runs == nullptr: count only.  Returns the number of non-empty runs or -1.
-static long rle_scan(const uint8_t *buf, size_t len, uint32_t W, uint32_t H, uint2 *runs, uint32_t dst0, uint32_t src0, char *err, size_t errn) {
-    const size_t total = (size_t)W * H;
-    size_t p = 0, pos = 8;
-    long cnt = 0;
-    while (p < total) {
-        if (len - pos < 4) { snprintf(err, errn, "depth payload truncated at byte %zu", pos); return -1; }
-        const uint32_t n_empty = rd32(buf + pos); pos += 4;
-        if ((size_t)n_empty > total - p) { snprintf(err, errn, "run of %u empty pixels overruns the image (reference panics, biwi.rs:92)", n_empty); return -1; }
-        p += n_empty;
-        if (len - pos < 4) { snprintf(err, errn, "depth payload truncated at byte %zu", pos); return -1; }
-        const uint32_t n_full = rd32(buf + pos); pos += 4;
-        if ((size_t)n_full > total - p) { snprintf(err, errn, "run of %u pixels overruns the image (reference panics, biwi.rs:97)", n_full); return -1; }
-        if ((len - pos) / 2 < n_full) { snprintf(err, errn, "depth payload truncated inside a run at byte %zu", pos); return -1; }
-        if (n_full) {
-            if (runs) runs[cnt] = make_uint2(dst0 + (uint32_t)p, src0 + (uint32_t)(pos >> 1));
-            ++cnt;
-        }
-        pos += (size_t)n_full * 2;
-        p += n_full;
-    }
-    return cnt;
-}
-
-template <typename T>
-static int grow_pinned(T **buf, size_t *cap, size_t need) {
-    if (need <= *cap) return DH_OK;
-    if (*buf) (void)hipHostFree(*buf);
-    *buf = nullptr; *cap = 0;
-    const size_t want = need + need / 4 + 4096;
-    void *q = nullptr;
-    hipError_t e = hipHostMalloc(&q, want * sizeof(T), hipHostMallocDefault);
-    if (e != hipSuccess) return fail(DH_ENOMEM, "hipHostMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
-    *buf = (T *)q; *cap = want;
-    return DH_OK;
-}
-template <typename T>
-static int grow_device(T **buf, size_t *cap, size_t need) {
-    if (need <= *cap) return DH_OK;
-    if (*buf) (void)hipFree(*buf);
-    *buf = nullptr; *cap = 0;
-    const size_t want = need + need / 4 + 4096;
-    void *q = nullptr;
-    hipError_t e = hipMalloc(&q, want * sizeof(T));
-    if (e != hipSuccess) return fail(DH_ENOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
-    *buf = (T *)q; *cap = want;
-    return DH_OK;
-}
-
-// Validates every payload, packs blob + run table into pinned memory and sizes the device buffers.  Nothing has been
-// launched when this fails.  blob_off[i] = byte offset of frame i's payload in the blob (16-byte aligned).
-static int rle_prepare(dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t *W_, uint32_t *H_,
-                       std::vector<size_t> &blob_off) {
-    if (n <= 0) return fail(DH_EINVAL, "batch size must be positive");
-    for (int i = 0; i < n; ++i) {
-        if (!bufs[i]) return fail(DH_EINVAL, "frame %d: NULL payload", i);
-        if (lens[i] < 8) return fail(DH_EINVAL, "frame %d: depth payload truncated in the header", i);      // read_u32 fails (biwi.rs:83-84)
-    }
-    const uint32_t W = rd32(bufs[0]), H = rd32(bufs[0] + 4);
-    if (W == 0 || H == 0 || (uint64_t)W * H > 0x7fffffffull) return fail(DH_ESIZE, "frame 0: unsupported image size %ux%u", W, H);
-    if ((uint64_t)n * W * H > 0xffffffffull) return fail(DH_ESIZE, "batch of %d frames of %ux%u exceeds 2^32 pixels; split it", n, W, H);
-    blob_off.assign((size_t)n + 1, 0);
-    for (int i = 0; i < n; ++i) blob_off[i + 1] = blob_off[i] + ((lens[i] + 15) & ~(size_t)15);
-    if (blob_off[n] / 2 > 0xffffffffull) return fail(DH_ESIZE, "payloads exceed 8 GiB; split the batch");
-    // pass A: validate + count
-    std::vector<long> counts((size_t)n, 0);
-    std::vector<std::string> errs((size_t)n);
-    parallel_for(n, p->knobs.host_threads, [&](int i) {
-        char e[160] = "";
-        if (rd32(bufs[i]) != W || rd32(bufs[i] + 4) != H) { snprintf(e, sizeof e, "image is %ux%u, frame 0 is %ux%u", rd32(bufs[i]), rd32(bufs[i] + 4), W, H); counts[i] = -1; }
-        else counts[i] = rle_scan(bufs[i], lens[i], W, H, nullptr, 0, 0, e, sizeof e);
-        if (counts[i] < 0) errs[i] = e;
-    });
-    for (int i = 0; i < n; ++i)
-        if (counts[i] < 0) return fail(DH_EINVAL, "frame %d: %s", i, errs[i].c_str());
-    int rc = grow_pinned(&p->pin_begin, &p->pin_begin_cap, (size_t)n + 1);
+// Validates every payload (dh_rle_plan_), packs blob + run table into pinned memory (dh_rle_pack_) and sizes the device
+// buffers.  Nothing has been launched when this fails.
+static_assert(sizeof(DhRun) == sizeof(uint2), "run table entries are uint2 on the device");
+static int rle_prepare(dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, RlePlan &plan) {
+    int rc = dh_rle_plan_(bufs, lens, n, p->knobs.host_threads, plan);
     if (rc) return rc;
-    p->pin_begin[0] = 0;
-    size_t nruns = 0;
-    for (int i = 0; i < n; ++i) { nruns += (size_t)counts[i]; if (nruns > 0xffffffffull) return fail(DH_ESIZE, "too many runs"); p->pin_begin[i + 1] = (uint32_t)nruns; }
-    rc = grow_pinned(&p->pin_blob, &p->pin_blob_cap, blob_off[n]);
-    if (rc == DH_OK) rc = grow_pinned(&p->pin_runs, &p->pin_runs_cap, std::max<size_t>(nruns, 1));
-    if (rc == DH_OK) rc = grow_device(&p->dev_blob, &p->dev_blob_cap, blob_off[n]);
-    if (rc == DH_OK) rc = grow_device(&p->dev_runs, &p->dev_runs_cap, std::max<size_t>(nruns, 1));
+    const size_t blob_bytes = plan.blob_off[n];
+    rc = grow_pinned(&p->pin_begin, &p->pin_begin_cap, (size_t)n + 1);
+    if (rc == DH_OK) rc = grow_pinned(&p->pin_blob, &p->pin_blob_cap, blob_bytes);
+    if (rc == DH_OK) rc = grow_pinned(&p->pin_runs, &p->pin_runs_cap, std::max<size_t>(plan.nruns, 1));
+    if (rc == DH_OK) rc = grow_device(&p->dev_blob, &p->dev_blob_cap, blob_bytes);
+    if (rc == DH_OK) rc = grow_device(&p->dev_runs, &p->dev_runs_cap, std::max<size_t>(plan.nruns, 1));
     if (rc == DH_OK) rc = grow_device(&p->dev_begin, &p->dev_begin_cap, (size_t)n + 1);
     if (rc) return rc;
-    // pass B: pack (the payload bytes as they are; the run table points into them)
-    parallel_for(n, p->knobs.host_threads, [&](int i) {
-        memcpy(p->pin_blob + blob_off[i], bufs[i], lens[i]);
-        char e[8];
-        (void)rle_scan(bufs[i], lens[i], W, H, p->pin_runs + p->pin_begin[i], (uint32_t)((size_t)i * W * H), (uint32_t)(blob_off[i] >> 1), e, sizeof e);
-    });
-    *W_ = W; *H_ = H;
+    memcpy(p->pin_begin, plan.run_begin.data(), ((size_t)n + 1) * sizeof(uint32_t));
+    dh_rle_pack_(bufs, lens, n, p->knobs.host_threads, plan, p->pin_blob, (DhRun *)p->pin_runs);
     return DH_OK;
 }
 
@@ -1260,16 +895,17 @@ static int rle_upload_decode(dh_predictor *p, const std::vector<size_t> &blob_of
     return DH_OK;
 }
 
-extern "C" int dh_biwi_decode_depth_device(dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, uint16_t *frames_dev,
+static int biwi_decode_depth_device_(dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, uint16_t *frames_dev,
                                            size_t cap_px, uint32_t *w, uint32_t *h) {
     if (!p || !bufs || !lens || !w || !h) return fail(DH_EINVAL, "dh_biwi_decode_depth_device: NULL argument");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->own_stream));             // the pinned staging buffers are free
     HIP_TRY(hipStreamSynchronize(p->copy_stream));
-    std::vector<size_t> blob_off;
-    uint32_t W = 0, H = 0;
-    int rc = rle_prepare(p, bufs, lens, n, &W, &H, blob_off);
+    RlePlan plan;
+    int rc = rle_prepare(p, bufs, lens, n, plan);
     if (rc) return rc;
+    const std::vector<size_t> &blob_off = plan.blob_off;
+    const uint32_t W = plan.W, H = plan.H;
     *w = W; *h = H;
     if (!frames_dev) return DH_OK;                            // size query (validates as well)
     if (cap_px < (size_t)n * W * H) return fail(DH_EINVAL, "output holds %zu pixels, the batch has %zu", cap_px, (size_t)n * W * H);
@@ -1285,7 +921,7 @@ extern "C" int dh_biwi_decode_depth_device(dh_predictor *p, const uint8_t *const
     return DH_OK;
 }
 
-extern "C" int dh_predict_batch_rle(dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, const float K[9],
+static int predict_batch_rle_(dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, const float K[9],
                                     const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out) {
     if (!p || !bufs || !lens || !K || !out) return fail(DH_EINVAL, "dh_predict_batch_rle: NULL argument");
     if (n == 0) return DH_OK;
@@ -1297,18 +933,20 @@ extern "C" int dh_predict_batch_rle(dh_predictor *p, const uint8_t *const *bufs,
         const int m = std::min(slice, n - f0);
         HIP_TRY(hipStreamSynchronize(s));                         // pinned staging and device blob of the previous slice are free
         HIP_TRY(hipStreamSynchronize(p->copy_stream));
-        std::vector<size_t> blob_off;
-        uint32_t W = 0, H = 0;
-        int rc = rle_prepare(p, bufs + f0, lens + f0, m, &W, &H, blob_off);   // validates: nothing launched on failure
+        RlePlan plan;
+        int rc = rle_prepare(p, bufs + f0, lens + f0, m, plan);   // validates: nothing launched on failure
         if (rc) return rc;
+        const std::vector<size_t> &blob_off = plan.blob_off;
+        const uint32_t W = plan.W, H = plan.H;
         const int w = (int)W, h = (int)H;
         rc = reserve(p, m, w, h);
         if (rc == DH_OK) rc = ensure_frame_staging(p, (size_t)m * W * H * sizeof(uint16_t));
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(p->dev_begin, p->pin_begin, ((size_t)m + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        if (midp_guess) HIP_TRY(hipMemcpyAsync(p->ws_midp, midp_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice, s));
-        if (rot_guess) HIP_TRY(hipMemcpyAsync(p->ws_rot, rot_guess + (size_t)f0 * 3, (size_t)m * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-        if (guess_mask) HIP_TRY(hipMemcpyAsync(p->ws_mask, guess_mask + f0, (size_t)m, hipMemcpyHostToDevice, s));
+        SmallStage st;
+        rc = small_stage(p, m, &st);
+        if (rc == DH_OK) rc = upload_guesses(p, st, f0, m, midp_guess, rot_guess, guess_mask, s);
+        if (rc) return rc;
         const int chunk = p->debug ? m : std::min(m, p->knobs.stage_chunk * 2);   // compressed chunks are small: twice the raw chunk
         int ci = 0;
         for (int c0 = 0; c0 < m; c0 += chunk, ++ci) {
@@ -1320,23 +958,23 @@ extern "C" int dh_predict_batch_rle(dh_predictor *p, const uint8_t *const *bufs,
                                              rot_guess ? p->ws_rot + (size_t)c0 * 3 : nullptr, guess_mask ? p->ws_mask + c0 : nullptr, p->ws_poses + c0, s);
             if (rc) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamSynchronize(s); return rc; }
         }
-        HIP_TRY(hipMemcpyAsync(out + f0, p->ws_poses, (size_t)m * sizeof(dh_pose), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        rc = download_poses(p, st, m, out + f0, s);
+        if (rc) return rc;
     }
     return DH_OK;
 }
 
 // ------------------------------------------------------------------ hipGraph capture of one batch
-// For launch-bound use (small frames / single frames, BASELINE config 5): the memset + three kernel
-// launches of one dh_predict_batch_device call are captured once and replayed with one host call.
-extern "C" int dh_graph_destroy(dh_predictor *p) {
+// For launch-bound use (small frames / single frames, BASELINE config 5): the zero-fill and the kernel
+// launches (k_boxsum ... k_cluster) of one dh_predict_batch_device call are captured once and replayed with one host call.
+static int graph_destroy_(dh_predictor *p) {
     if (!p) return fail(DH_EINVAL, "NULL predictor");
     drop_graph(p);
     p->graph_stale = false;
     return DH_OK;
 }
 
-extern "C" int dh_graph_capture(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+static int graph_capture_(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                                 const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_graph_capture: NULL argument");
     if (n <= 0) return fail(DH_EINVAL, "batch size must be positive");
@@ -1359,7 +997,7 @@ extern "C" int dh_graph_capture(dh_predictor *p, const uint16_t *frames, int n, 
     return DH_OK;
 }
 
-extern "C" int dh_graph_launch(dh_predictor *p, void *stream) {
+static int graph_launch_(dh_predictor *p, void *stream) {
     if (!p) return fail(DH_EINVAL, "NULL predictor");
     if (p->graph_stale) return fail(DH_ESTATE, "the captured batch is stale: the workspace was reallocated after dh_graph_capture (larger batch, other frame size or debug taps); capture again");
     if (!p->graph_exec) return fail(DH_ESTATE, "no captured batch (dh_graph_capture)");
@@ -1394,23 +1032,13 @@ static int aux_reserve(dh_predictor *p, int n, int w, int h, size_t out_bytes) {
     return DH_OK;
 }
 
-// imageproc 0.12.0 filter::gaussian_kernel_f32(sigma) (crate source not in the container; PARITY UNPINNED): radius
-// ceil(2 sigma), taps = the zero-mean normal density at 0, 1, ..., radius mirrored, NOT renormalised;
-// gaussian(x, r) = ((2.0 * PI).sqrt() * r).recip() * (-x.powi(2) / (2.0 * r.powi(2))).exp(), all in f32.
+// Taps of imageproc's gaussian_kernel_f32 (dh_blur_taps_, dh_host.cpp; parity unpinned), uploaded once per sigma.
 static int blur_kernel(dh_predictor *p) {
     const float sigma = p->params.gaussian_sigma;
     if (p->blur_kern && p->blur_sigma == sigma) return DH_OK;
-    if (!(sigma > 0.0f)) return fail(DH_EINVAL, "gaussian_blur_f32 needs sigma > 0 (the reference asserts)");
-    const float r2 = ceilf(2.0f * sigma);
-    if (!(r2 <= 2048.0f)) return fail(DH_ESIZE, "blur radius %g too large", (double)r2);
-    const int radius = (int)r2;
-    std::vector<float> k((size_t)2 * radius + 1);
-    const float norm = 1.0f / (sqrtf(2.0f * 3.14159274101257324f) * sigma);
-    for (int i = 0; i <= radius; ++i) {
-        const float x = (float)i;
-        const float v = norm * expf(-(x * x) / (2.0f * (sigma * sigma)));
-        k[radius + i] = v; k[radius - i] = v;
-    }
+    std::vector<float> k;
+    int rc0 = dh_blur_taps_(sigma, k);
+    if (rc0) return rc0;
     HIP_TRY(hipDeviceSynchronize());
     if (p->blur_kern) (void)hipFree(p->blur_kern);
     p->blur_kern = nullptr;
@@ -1425,7 +1053,7 @@ static int aux_run(dh_predictor *p, const uint16_t *frames, int n, int w, int h,
                    uint16_t *hough, hipStream_t s, bool blur = false, dh_pose *poses2d = nullptr) {
     const Geom &g = p->geom;
     float kinv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, kid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (K) mat3_inv_f32(K, kinv);
+    if (K) dh_mat3_inv_f32_(K, kinv);
     HIP_TRY(hipMemsetAsync(p->counters, 0, (size_t)p->cap_frames * sizeof(uint32_t), s));   // hit counters only
     HIP_TRY(hipMemsetAsync(p->counters + (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3), 0,
                            (size_t)p->cap_frames * ((size_t)p->geom.flag_words + (size_t)p->geom.tiles_x * p->geom.tiles_y) * sizeof(uint32_t), s));   // tile flags, window counts
@@ -1456,7 +1084,7 @@ static int aux_run(dh_predictor *p, const uint16_t *frames, int n, int w, int h,
     return DH_OK;
 }
 
-extern "C" int dh_predict_mask_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask, void *stream) {
+static int predict_mask_device_(dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask, void *stream) {
     if (!p || !frames || !mask) return fail(DH_EINVAL, "dh_predict_mask_device: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     DeviceGuard guard(p->device);
@@ -1471,7 +1099,7 @@ extern "C" int dh_predict_mask_device(dh_predictor *p, const uint16_t *frames, i
     return DH_OK;
 }
 
-extern "C" int dh_hough_image_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+static int hough_image_device_(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                                      uint16_t *out, void *stream) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_hough_image_device: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
@@ -1508,7 +1136,7 @@ static int stage_frames(dh_predictor *p, const uint16_t *frames, int n, int w, i
     return DH_OK;
 }
 
-extern "C" int dh_predict_mask(dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask) {
+static int predict_mask_(dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask) {
     if (!p || !frames || !mask) return fail(DH_EINVAL, "dh_predict_mask: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     HIP_TRY(hipSetDevice(p->device));
@@ -1526,7 +1154,7 @@ extern "C" int dh_predict_mask(dh_predictor *p, const uint16_t *frames, int n, i
     return DH_OK;
 }
 
-extern "C" int dh_hough_image(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *out) {
+static int hough_image_(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *out) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_hough_image: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     HIP_TRY(hipSetDevice(p->device));
@@ -1564,21 +1192,21 @@ static int hough2d_device(dh_predictor *p, const uint16_t *frames, int n, int w,
     return DH_OK;
 }
 
-extern "C" int dh_build_hough_image_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+static int build_hough_image_device_(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                                            uint16_t *out, void *stream) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_build_hough_image_device: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     return hough2d_device(p, frames, n, w, h, K, out, nullptr, (hipStream_t)stream);
 }
 
-extern "C" int dh_predict_from2dhough_device(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
+static int predict_from2dhough_device_(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9],
                                              dh_pose *out, void *stream) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_from2dhough_device: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     return hough2d_device(p, frames, n, w, h, K, nullptr, out, (hipStream_t)stream);
 }
 
-extern "C" int dh_build_hough_image(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *out) {
+static int build_hough_image_(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *out) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_build_hough_image: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     HIP_TRY(hipSetDevice(p->device));
@@ -1598,7 +1226,7 @@ extern "C" int dh_build_hough_image(dh_predictor *p, const uint16_t *frames, int
     return DH_OK;
 }
 
-extern "C" int dh_predict_from2dhough(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], dh_pose *out) {
+static int predict_from2dhough_(dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], dh_pose *out) {
     if (!p || !frames || !K || !out) return fail(DH_EINVAL, "dh_predict_from2dhough: NULL argument");
     if (n <= 0) return n == 0 ? DH_OK : fail(DH_EINVAL, "negative batch size");
     HIP_TRY(hipSetDevice(p->device));
@@ -1609,22 +1237,23 @@ extern "C" int dh_predict_from2dhough(dh_predictor *p, const uint16_t *frames, i
         const int m = std::min(slice, n - f0);
         rc = aux_reserve(p, m, w, h, (size_t)m * w * h * sizeof(uint16_t));
         if (rc == DH_OK) rc = stage_frames(p, frames + (size_t)f0 * w * h, m, w, h);
+        SmallStage st;
+        if (rc == DH_OK) rc = small_stage(p, m, &st);
         if (rc == DH_OK) rc = aux_run(p, p->ws_frames, m, w, h, K, nullptr, (uint16_t *)p->aux_out, p->own_stream, true, p->ws_poses);
+        if (rc == DH_OK) rc = download_poses(p, st, m, out + f0, p->own_stream);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(out + f0, p->ws_poses, (size_t)m * sizeof(dh_pose), hipMemcpyDeviceToHost, p->own_stream));
-        HIP_TRY(hipStreamSynchronize(p->own_stream));
     }
     return DH_OK;
 }
 
 // ------------------------------------------------------------------ profiling
-extern "C" int dh_set_profiling(dh_predictor *p, int on) {
+static int set_profiling_(dh_predictor *p, int on) {
     if (!p) return fail(DH_EINVAL, "NULL predictor");
     p->profiling = on != 0;
     p->ev_valid = false;
     return DH_OK;
 }
-extern "C" int dh_get_timing(dh_predictor *p, dh_timing *out) {
+static int get_timing_(dh_predictor *p, dh_timing *out) {
     if (!p || !out) return fail(DH_EINVAL, "NULL argument");
     if (!p->ev_valid) return fail(DH_ESTATE, "no profiled batch yet (dh_set_profiling + a batch)");
     HIP_TRY(hipEventSynchronize(p->ev[3]));
@@ -1640,7 +1269,7 @@ extern "C" int dh_get_timing(dh_predictor *p, dh_timing *out) {
 }
 
 // ------------------------------------------------------------------ parity taps
-extern "C" int dh_debug_enable(dh_predictor *p, int on) {
+static int debug_enable_(dh_predictor *p, int on) {
     if (!p) return fail(DH_EINVAL, "NULL predictor");
     p->debug = on != 0;
     if (!p->debug) p->dbg_valid = false;
@@ -1660,7 +1289,7 @@ static int tap_ready_dbg(dh_predictor *p) {
     if (!p->dbg_valid) return fail(DH_ESTATE, "debug taps were not enabled for the last batch");
     return DH_OK;
 }
-extern "C" int dh_debug_leaf_indices(dh_predictor *p, int32_t *out, size_t cap) {
+static int debug_leaf_indices_(dh_predictor *p, int32_t *out, size_t cap) {
     int rc = tap_ready_dbg(p);
     if (rc) return rc;
     size_t n = (size_t)p->last_n * p->geom.npatch * p->n_trees;
@@ -1668,7 +1297,7 @@ extern "C" int dh_debug_leaf_indices(dh_predictor *p, int32_t *out, size_t cap) 
     if (n) HIP_TRY(hipMemcpy(out, p->dbg_leaf, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return DH_OK;
 }
-extern "C" int dh_debug_patch_flags(dh_predictor *p, uint8_t *out, size_t cap) {
+static int debug_patch_flags_(dh_predictor *p, uint8_t *out, size_t cap) {
     int rc = tap_ready_dbg(p);
     if (rc) return rc;
     size_t n = (size_t)p->last_n * p->geom.npatch;
@@ -1676,7 +1305,7 @@ extern "C" int dh_debug_patch_flags(dh_predictor *p, uint8_t *out, size_t cap) {
     if (n) HIP_TRY(hipMemcpy(out, p->dbg_flags, n, hipMemcpyDeviceToHost));
     return DH_OK;
 }
-extern "C" int dh_debug_grids(dh_predictor *p, uint32_t *pos_grid, uint32_t *rot_grid) {
+static int debug_grids_(dh_predictor *p, uint32_t *pos_grid, uint32_t *rot_grid) {
     int rc = tap_ready(p);
     if (rc) return rc;
     const uint32_t *pg = p->counters + p->cap_frames, *rg = pg + (size_t)p->cap_frames * DH_POSGRID;
@@ -1684,14 +1313,14 @@ extern "C" int dh_debug_grids(dh_predictor *p, uint32_t *pos_grid, uint32_t *rot
     if (rot_grid) HIP_TRY(hipMemcpy(rot_grid, rg, (size_t)p->last_n * DH_GRID3 * 4, hipMemcpyDeviceToHost));
     return DH_OK;
 }
-extern "C" int dh_debug_hit_counts(dh_predictor *p, uint32_t *out) {
+static int debug_hit_counts_(dh_predictor *p, uint32_t *out) {
     int rc = tap_ready(p);
     if (rc) return rc;
     if (!out) return fail(DH_EINVAL, "NULL output");
     HIP_TRY(hipMemcpy(out, p->counters, (size_t)p->last_n * 4, hipMemcpyDeviceToHost));
     return DH_OK;
 }
-extern "C" int dh_debug_geometry(dh_predictor *p, int32_t out[10]) {
+static int debug_geometry_(dh_predictor *p, int32_t out[10]) {
     if (!p || !out) return fail(DH_EINVAL, "NULL argument");
     if (p->cap_frames == 0) return fail(DH_ESTATE, "no workspace yet (dh_predictor_reserve or a batch)");
     const Geom &g = p->geom;
@@ -1700,14 +1329,14 @@ extern "C" int dh_debug_geometry(dh_predictor *p, int32_t out[10]) {
     memcpy(out, v, sizeof v);
     return DH_OK;
 }
-extern "C" int dh_debug_guesses(dh_predictor *p, int32_t *out) {
+static int debug_guesses_(dh_predictor *p, int32_t *out) {
     int rc = tap_ready_dbg(p);
     if (rc) return rc;
     if (!out) return fail(DH_EINVAL, "NULL output");
     HIP_TRY(hipMemcpy(out, p->dbg_guess, (size_t)p->last_n * 6 * 4, hipMemcpyDeviceToHost));
     return DH_OK;
 }
-extern "C" int dh_debug_meanshift(dh_predictor *p, int which, int32_t *trace, uint32_t *steps) {
+static int debug_meanshift_(dh_predictor *p, int which, int32_t *trace, uint32_t *steps) {
     int rc = tap_ready_dbg(p);
     if (rc) return rc;
     if (which < 0 || which > 1) return fail(DH_EINVAL, "which must be 0 or 1");
@@ -1717,7 +1346,7 @@ extern "C" int dh_debug_meanshift(dh_predictor *p, int which, int32_t *trace, ui
     if (steps) HIP_TRY(hipMemcpy(steps, p->dbg_steps + (size_t)which * p->last_n, (size_t)p->last_n * 4, hipMemcpyDeviceToHost));
     return DH_OK;
 }
-extern "C" int dh_debug_votes(dh_predictor *p, int frame, int which, int32_t *out, size_t cap, size_t *count) {
+static int debug_votes_(dh_predictor *p, int frame, int which, int32_t *out, size_t cap, size_t *count) {
     int rc = tap_ready(p);
     if (rc) return rc;
     if (frame < 0 || frame >= p->last_n || which < 0 || which > 1 || !count) return fail(DH_EINVAL, "bad frame / which / count");
@@ -1745,3 +1374,47 @@ extern "C" int dh_debug_votes(dh_predictor *p, int frame, int which, int32_t *ou
     if (ncopy && out) HIP_TRY(hipMemcpy(out, p->dbg_votes, ncopy * 16, hipMemcpyDeviceToHost));
     return DH_OK;
 }
+
+// ------------------------------------------------------------------ the C ABI
+// Every entry point of include/depthhead_hip.h runs its body (the *_ functions above) inside dh_guard_: the header promises
+// that nothing throws or aborts across the boundary, and the bodies allocate (std::vector, std::string, std::thread).
+#define DH_API(name, params, args) \
+    extern "C" int dh_##name params { return dh_guard_("dh_" #name, [&]() -> int { return name##_ args; }); }
+DH_API(forest_create, (const dh_forest_desc *d, dh_forest **out), (d, out))
+DH_API(forest_destroy, (dh_forest *f), (f))
+DH_API(forest_info, (const dh_forest *f, uint32_t *n_trees, uint32_t *n_nodes, uint32_t *n_leaves, uint32_t *max_depth), (f, n_trees, n_nodes, n_leaves, max_depth))
+DH_API(patch_grid, (const dh_params *p, int w, int h, int *nx, int *ny), (p, w, h, nx, ny))
+DH_API(predictor_destroy, (dh_predictor *p), (p))
+DH_API(predictor_create, (const dh_forest *f, const dh_params *prm, int device, dh_predictor **out), (f, prm, device, out))
+DH_API(predictor_update_sigma, (dh_predictor *p, float val), (p, val))
+DH_API(predictor_sigma, (const dh_predictor *p, float *out), (p, out))
+DH_API(predictor_reserve, (dh_predictor *p, int n, int w, int h), (p, n, w, h))
+DH_API(predict_batch_device, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out, void *stream_), (p, frames, n, w, h, K, midp_guess, rot_guess, guess_mask, out, stream_))
+DH_API(predict_batch, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out), (p, frames, n, w, h, K, midp_guess, rot_guess, guess_mask, out))
+DH_API(host_alloc, (size_t bytes, void **out), (bytes, out))
+DH_API(host_free, (void *ptr), (ptr))
+DH_API(biwi_decode_depth_device, (dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, uint16_t *frames_dev, size_t cap_px, uint32_t *w, uint32_t *h), (p, bufs, lens, n, frames_dev, cap_px, w, h))
+DH_API(predict_batch_rle, (dh_predictor *p, const uint8_t *const *bufs, const size_t *lens, int n, const float K[9], const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out), (p, bufs, lens, n, K, midp_guess, rot_guess, guess_mask, out))
+DH_API(graph_destroy, (dh_predictor *p), (p))
+DH_API(graph_capture, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out), (p, frames, n, w, h, K, midp_guess, rot_guess, guess_mask, out))
+DH_API(graph_launch, (dh_predictor *p, void *stream), (p, stream))
+DH_API(predict_mask_device, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask, void *stream), (p, frames, n, w, h, mask, stream))
+DH_API(hough_image_device, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *out, void *stream), (p, frames, n, w, h, K, out, stream))
+DH_API(predict_mask, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, uint8_t *mask), (p, frames, n, w, h, mask))
+DH_API(hough_image, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *out), (p, frames, n, w, h, K, out))
+DH_API(build_hough_image_device, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *out, void *stream), (p, frames, n, w, h, K, out, stream))
+DH_API(predict_from2dhough_device, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], dh_pose *out, void *stream), (p, frames, n, w, h, K, out, stream))
+DH_API(build_hough_image, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], uint16_t *out), (p, frames, n, w, h, K, out))
+DH_API(predict_from2dhough, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], dh_pose *out), (p, frames, n, w, h, K, out))
+DH_API(set_profiling, (dh_predictor *p, int on), (p, on))
+DH_API(get_timing, (dh_predictor *p, dh_timing *out), (p, out))
+DH_API(debug_enable, (dh_predictor *p, int on), (p, on))
+DH_API(debug_leaf_indices, (dh_predictor *p, int32_t *out, size_t cap), (p, out, cap))
+DH_API(debug_patch_flags, (dh_predictor *p, uint8_t *out, size_t cap), (p, out, cap))
+DH_API(debug_grids, (dh_predictor *p, uint32_t *pos_grid, uint32_t *rot_grid), (p, pos_grid, rot_grid))
+DH_API(debug_hit_counts, (dh_predictor *p, uint32_t *out), (p, out))
+DH_API(debug_geometry, (dh_predictor *p, int32_t out[10]), (p, out))
+DH_API(debug_guesses, (dh_predictor *p, int32_t *out), (p, out))
+DH_API(debug_meanshift, (dh_predictor *p, int which, int32_t *trace, uint32_t *steps), (p, which, trace, steps))
+DH_API(debug_votes, (dh_predictor *p, int frame, int which, int32_t *out, size_t cap, size_t *count), (p, frame, which, out, cap, count))
+#undef DH_API

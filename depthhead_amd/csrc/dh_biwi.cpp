@@ -1,7 +1,7 @@
-// dh_biwi.hip -- BIWI Kinect Head Pose Database file formats:
+// dh_biwi.cpp -- BIWI Kinect Head Pose Database file formats:
 // host-side decoders feeding the frame batches of dh_predict_batch.  Restates the parsers of
 // /root/reference/src/db_reader/biwi.rs: read_depth (:81-103), read_cal (:27-60), read_gt (:63-77).
-// Byte / integer work and three f32 operations; no device code.
+// Byte / integer work and three f32 operations; no device code: plain C++ (builds with g++ for the sanitizer tests, tests/host/).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -9,15 +9,13 @@
 #include <string>
 #include <vector>
 
-#include "dh_internal.h"
-
-extern int dh_fail_(int code, const char *fmt, ...);   // dh_api.hip
+#include "dh_host.h"
 
 static inline uint32_t rd_u32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 
 // read_depth (biwi.rs:81-103): u32 width, u32 height, then runs { u32 n_empty; u32 n_full; u16 depth[n_full] }
 // (little endian) until width*height pixels are produced; empty pixels are 0.
-extern "C" int dh_biwi_decode_depth(const uint8_t *buf, size_t len, uint16_t *out, size_t cap_px, uint32_t *w, uint32_t *h) {
+static int decode_depth(const uint8_t *buf, size_t len, uint16_t *out, size_t cap_px, uint32_t *w, uint32_t *h) {
     if (!buf || !w || !h) return dh_fail_(DH_EINVAL, "dh_biwi_decode_depth: NULL argument");
     if (len < 8) return dh_fail_(DH_EINVAL, "depth file truncated in the header");          // read_u32 fails (:83-84)
     const uint32_t W = rd_u32(buf), H = rd_u32(buf + 4);
@@ -47,7 +45,7 @@ extern "C" int dh_biwi_decode_depth(const uint8_t *buf, size_t len, uint16_t *ou
 // read_cal (biwi.rs:27-60): the first three lines must each hold exactly three matches of the
 // regex (\d+[\.\d+]*) -- a digit followed by any run of digits, '.' and '+'; signs and exponents are
 // not part of a match -- each parsed by f32::from_str.
-extern "C" int dh_biwi_parse_cal(const char *text, size_t len, float K[9]) {
+static int parse_cal(const char *text, size_t len, float K[9]) {
     if (!text || !K) return dh_fail_(DH_EINVAL, "dh_biwi_parse_cal: NULL argument");
     size_t pos = 0;
     for (int j = 0; j < 3; ++j) {
@@ -77,7 +75,7 @@ extern "C" int dh_biwi_parse_cal(const char *text, size_t len, float K[9]) {
 
 // read_gt (biwi.rs:63-77): six little-endian f32: position (mm), rotation (degrees); the 2-D
 // position is IntrinsicMatrix::space_to_img_coord of the 3-D one (types.rs:424-428).
-extern "C" int dh_biwi_parse_pose(const uint8_t *buf, size_t len, const float K[9], float pos3d[3], float pos2d[2], float rot[3]) {
+static int parse_pose(const uint8_t *buf, size_t len, const float K[9], float pos3d[3], float pos2d[2], float rot[3]) {
     if (!buf || !K || !pos3d || !pos2d || !rot) return dh_fail_(DH_EINVAL, "dh_biwi_parse_pose: NULL argument");
     if (len < 24) return dh_fail_(DH_EINVAL, "pose file truncated (%zu of 24 bytes)", len);
     float v[6];
@@ -93,4 +91,15 @@ extern "C" int dh_biwi_parse_pose(const uint8_t *buf, size_t len, const float K[
     pos2d[0] = r[0] / r[2];
     pos2d[1] = r[1] / r[2];
     return DH_OK;
+}
+
+// ---- the C ABI (nothing throws across it: parse_cal builds std::string tokens)
+extern "C" int dh_biwi_decode_depth(const uint8_t *buf, size_t len, uint16_t *out, size_t cap_px, uint32_t *w, uint32_t *h) {
+    return dh_guard_("dh_biwi_decode_depth", [&] { return decode_depth(buf, len, out, cap_px, w, h); });
+}
+extern "C" int dh_biwi_parse_cal(const char *text, size_t len, float K[9]) {
+    return dh_guard_("dh_biwi_parse_cal", [&] { return parse_cal(text, len, K); });
+}
+extern "C" int dh_biwi_parse_pose(const uint8_t *buf, size_t len, const float K[9], float pos3d[3], float pos2d[2], float rot[3]) {
+    return dh_guard_("dh_biwi_parse_pose", [&] { return parse_pose(buf, len, K, pos3d, pos2d, rot); });
 }

@@ -1,10 +1,10 @@
 // dh_internal.h -- structures shared by the host runtime (dh_api.hip) and the gfx950 kernels
-// (dh_kernels.hip).  Not part of the ABI.
+// (k_*.hip): kernel argument blocks, device views of the forest, record layouts, launchers.  Not part of the ABI.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/depthhead_hip.h"
+#include "dh_host.h"
 
 #define DH_GRID 20             // GUESS_GRID_PARTS and the mean-shift kernel edge
 #define DH_GRID3 8000          // 20^3
@@ -81,15 +81,6 @@ struct __attribute__((aligned(16))) HitRot {
     uint32_t hi;
     uint32_t rb;       // index of the leaf's first rotation cell
     uint32_t n_rot;    // distinct fine bins | distinct guess-grid cells << 16
-};
-
-// General-path node with integer split bounds (k_traverse<false, true>, built on the host by dh_predictor_create).
-struct __attribute__((aligned(16))) NodeG {
-    uint8_t  r1[4], r2[4];      // x0, y0, x1, y1 of the two rectangles
-    int64_t  ilo;
-    int32_t  child_zero, child_one;
-    uint32_t amb;               // integers strictly between ilo and ihi (saturating)
-    uint32_t cc;                // C1 | C2 << 16
 };
 
 struct TraverseArgs {
@@ -276,7 +267,7 @@ hipError_t dh_launch_rle_decode(const RleArgs &a, hipStream_t s);
 hipError_t dh_launch_zero(void *ptr, size_t bytes, hipStream_t s);   // ptr, bytes multiples of 16
 hipError_t dh_launch_mask(const AuxArgs &a, hipStream_t s);
 hipError_t dh_launch_hough2d(const AuxArgs &a, uint16_t *out, hipStream_t s);
-hipError_t dh_kernels_init();
+hipError_t dh_kernels_init(int device);   // once per device: dynamic-LDS limit of the walk kernel
 hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s);
 hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int swz_q, uint32_t area, void *out, void *out_a, uint32_t *any_amb,
                                    uint32_t *amb_list, uint32_t n_amb, hipStream_t s);
@@ -290,9 +281,4 @@ hipError_t dh_launch_region(const ClusterArgs &a, hipStream_t s);
 hipError_t dh_launch_votes_dump(const VotesDumpArgs &a, hipStream_t s);
 hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s);
 hipError_t dh_launch_pixflags(const PixFlagArgs &a, hipStream_t s);
-// rw, rh > 0 selects the uniform (box-sum region) layout, 0 the general (SAT) layout
-size_t dh_traverse_lds_bytes(int px, int py, int step, int sw, int sh, int top_words, int rw, int rh);
 hipError_t dh_launch_top_build(const DevForest &f, const void *nodes_a, uint32_t n_amb, int top_levels, uint32_t *out, hipStream_t s);
-int dh_traverse_row_stride(int px, int step, int sw, int rw);
-// uniform path: column de-interleave factor (log2) for this stride of window positions, plane size, padded row stride
-void dh_traverse_swizzle(int px, int step, int sw, int rw, int *swz_log2, int *swz_q, int *ss_row);

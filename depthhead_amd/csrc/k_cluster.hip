@@ -1,0 +1,497 @@
+// k_cluster.hip -- initial guesses and both mean shifts -> pose (k_cluster, k_region), vote-dump tap
+//
+// One of the kernel translation units of libdepthhead_hip.so (hand-written HIP for gfx950: wave64, 160 KB LDS/CU;
+// no MFMA anywhere -- there is no dense contraction on this path).  Overview of the pipeline: dh_api.hip.
+#include "dh_device.h"
+
+// ================================================================== k_cluster
+// One 1024-thread workgroup per (frame, accumulator): blockIdx.x = 0 head position (`mid`),
+// 1 rotation (`rot`).
+//
+// The reference keeps both accumulators as unbounded HashMap<(i32,i32,i32),u32>
+// (meanshift.rs:14-68) and reads a 20^3 window per iteration.  Here a 26^3-cell REGION of the
+// accumulator around the current position is materialised in LDS straight from the hit records
+// (integer atomics: exact, order-free); hits whose vote bounding box misses the region are dropped
+// with one test.  The mean shift then iterates inside the region and the gather is repeated only
+// when the 20^3 window would leave it (it moves by a few cells per step after the first).
+// The weighted sums run over the non-zero window cells in the reference's x -> y -> z order
+// (meanshift.rs:344-381) as a strictly sequential f32 chain on 4 lanes (num.x, num.y, num.z, den);
+// everything off that chain (cell compaction, kernel weight, products) is done by all threads.
+#define CL_THREADS 1024
+#define CL_WAVES (CL_THREADS / WAVE)
+#define CL_CHUNKS 8             // 8 * 1024 = 8192 >= 8000 window cells
+#define CL_PROD_CAP 512         // products staged per pass (x4 floats = 8 KB)
+#define CL_LIST (CL_PROD_CAP * 4) // survivors of the region gathers' bounding-box tests listed in `prod` (2048)
+#define RG 26                   // region edge; the window may sit at offsets 0..RG-20 inside it
+#define RG3 (RG * RG * RG)
+static_assert(RG3 == DH_REGION_CELLS, "dh_internal.h: DH_REGION_CELLS");
+
+// exists c in [lo,hi] and d in [0,len) with c == start + d (i32 wrapping, like the reference's
+// release-mode `pos + offset`)?
+__device__ __forceinline__ bool range_hits_span(int32_t lo, int32_t hi, int32_t start, uint32_t len) {
+    uint32_t u = (uint32_t)start - (uint32_t)lo;
+    return u <= (uint32_t)hi - (uint32_t)lo || u >= (uint32_t)(1u - len);
+}
+
+// Position votes of hit record i that fall into the region: lane `sub` of `nsub` takes the leaf's offset votes
+// sub, sub + nsub, ... (prediction.rs:647-667).
+__device__ __forceinline__ void cluster_add_votes(const ClusterArgs &a, uint32_t *region, const HitRec *hits, const HitBox *box,
+                                                  uint32_t i, uint32_t sub, uint32_t nsub, const int32_t org[3]) {
+    const float4 rec = *(const float4 *)(hits + i);
+    const uint32_t v = box[i].v, fc = box[i].fc;
+    const uint32_t ob = __float_as_uint(rec.w), oe = ob + (fc >> 8);
+#pragma unroll 1
+    for (uint32_t o = ob + sub; o < oe; o += nsub) {
+        const float4 of = a.f.off4[o];
+        float nx = __fsub_rn(rec.x, of.x), ny = __fsub_rn(rec.y, of.y), nz = __fsub_rn(rec.z, of.z); // prediction.rs:647
+        if (nz < 0.0f) continue;                                                                      // :650
+        uint32_t dx = (uint32_t)f32_as_i32(nx) - (uint32_t)org[0];                                     // :667
+        uint32_t dy = (uint32_t)f32_as_i32(ny) - (uint32_t)org[1];
+        uint32_t dz = (uint32_t)f32_as_i32(__fdiv_rn(nz, (float)DH_ZSCALEFACTOR)) - (uint32_t)org[2];
+        if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], v);
+    }
+}
+
+// Shared-memory carve-up of k_cluster / k_region.
+struct ClShared {
+    uint32_t *region;              // [RG3]
+    float *prod;                   // [CL_PROD_CAP * 4], doubles as the survivor list of the gathers
+    unsigned long long *red64;     // [CL_WAVES]
+    uint32_t *red32;               // [CL_WAVES]
+    int32_t *s_pos;                // [3]
+    uint32_t *s_total;
+};
+
+// Initial guess of one accumulator into sh.s_pos (the caller synchronises before reading it): first strictly-greatest
+// cell, i.e. greatest value then smallest index (prediction.rs:694-702 for the 20x20 grid; :733-742 with the x-fastest
+// iteration order of meanshift.rs:114-138 for the 20^3 grid); all-zero grid -> index 0; then the caller's guesses (:437-460).
+__device__ __forceinline__ void cl_initial_guess(const ClusterArgs &a, const int which, const int frame, const ClShared sh) {
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    unsigned long long *red64 = sh.red64;
+    uint32_t *red32 = sh.red32;
+    int32_t *s_pos = sh.s_pos;
+    const uint8_t gmask = a.guess_mask ? a.guess_mask[frame] : 3;
+    {
+        const uint32_t *g = which == 0 ? a.pos_grid + (size_t)frame * DH_POSGRID : a.rot_grid + (size_t)frame * DH_GRID3;
+        const int ncell = which == 0 ? DH_POSGRID : DH_GRID3;
+        unsigned long long best = 0;   // (value << 32) | ~idx
+        for (int i = tid; i < ncell; i += CL_THREADS) {
+            uint32_t gv = g[i];
+            unsigned long long k = ((unsigned long long)gv << 32) | (uint32_t)(~(uint32_t)i);
+            if (gv && k > best) best = k;
+        }
+        for (int d = WAVE / 2; d; d >>= 1) { unsigned long long o = __shfl_down(best, d); if (o > best) best = o; }
+        if (lane == 0) red64[wave] = best;
+        __syncthreads();
+        best = red64[0];
+        for (int i = 1; i < CL_WAVES; ++i) if (red64[i] > best) best = red64[i];
+        const uint32_t best_idx = best ? ~(uint32_t)best : 0u;
+        __syncthreads();
+        if (which == 0) {
+            int gpw = a.w / DH_GRID, gph = a.h / DH_GRID;                 // :706-707
+            int mxg = best_idx % DH_GRID, myg = best_idx / DH_GRID;       // :708-709
+            // mean of the non-zero pixels of that image cell (:711-725)
+            const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
+            unsigned long long zs = 0; uint32_t zc = 0;
+            for (int i = tid; i < gpw * gph; i += CL_THREADS) {
+                int xx = gpw * mxg + i % gpw, yy = gph * myg + i / gpw;
+                uint32_t v = img[(size_t)yy * a.w + xx];
+                if (v) { zs += v; zc++; }
+            }
+            for (int d = WAVE / 2; d; d >>= 1) { zs += __shfl_down(zs, d); zc += __shfl_down(zc, d); }
+            if (lane == 0) { red64[wave] = zs; red32[wave] = zc; }
+            __syncthreads();
+            if (tid == 0) {
+                zs = 0; zc = 0;
+                for (int i = 0; i < CL_WAVES; ++i) { zs += red64[i]; zc += red32[i]; }
+                float meanz = zc ? (float)__ddiv_rn((double)zs, (double)zc) : 0.0f;
+                float mx = __fmul_rn(__fadd_rn((float)mxg, 0.5f), (float)gpw);       // :727-728
+                float my = __fmul_rn(__fadd_rn((float)myg, 0.5f), (float)gph);
+                float q[3];
+                to3d(a.kinv, mx, my, meanz, q);                                       // :729
+                int32_t gm[3] = {f32_as_i32(q[0]), f32_as_i32(q[1]), f32_as_i32(q[2]) / DH_ZSCALEFACTOR};  // :750
+                if (a.midp_guess && (gmask & 1)) {                                    // :437-441
+                    const float *mg = a.midp_guess + (size_t)frame * 3;
+                    gm[0] = f32_as_i32(mg[0]); gm[1] = f32_as_i32(mg[1]); gm[2] = f32_as_i32(mg[2]) / DH_ZSCALEFACTOR;
+                }
+                s_pos[0] = gm[0]; s_pos[1] = gm[1]; s_pos[2] = gm[2];
+            }
+        } else if (tid == 0) {
+            uint32_t rb[3] = {best_idx % DH_GRID, (best_idx / DH_GRID) % DH_GRID, best_idx / (DH_GRID * DH_GRID)};
+            for (int k = 0; k < 3; ++k) {
+                double deg = __ddiv_rn(__dadd_rn(__dmul_rn((double)rb[k], 360.0), 180.0), 20.0);   // :745-747
+                if (a.rot_guess && (gmask & 2))                                                   // :444-453
+                    deg = __dadd_rn(__ddiv_rn(__dmul_rn(a.rot_guess[(size_t)frame * 3 + k], 180.0), 3.14159), 180.0);
+                s_pos[k] = f64_as_i32(__ddiv_rn(__dmul_rn(deg, 120.0), 360.0));                   // :458-460
+            }
+        }
+    }
+}
+
+// Adds to the (zeroed) LDS region with origin `org` every vote of accumulator `which` that falls into it, from the hit
+// records [h0, h1) of the frame -- or, for rotation votes of forests with a leaf histogram, from the leaves [l0, l1).
+// Integer atomics: exact and order-free, so any split of the ranges over workgroups sums to the same region.
+__device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which, const int frame, const int32_t org[3],
+                                          const uint32_t h0, const uint32_t h1, const uint32_t l0, const uint32_t l1, const ClShared sh) {
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    uint32_t *region = sh.region;
+    float *prod = sh.prod;
+    uint32_t &s_total = *sh.s_total;
+    const HitRec *hits = a.hits + (size_t)frame * a.hits_cap;
+    const HitBox *box = a.hit_box + (size_t)frame * a.hits_cap;
+    const HitRot *hr = a.hit_rot + (size_t)frame * a.hits_cap;
+    if (which == 0) {
+        // Two steps: (1) every thread tests the vote bounding boxes of its records against the region and
+        // appends the survivors to a list (in `prod`, idle now; a record that finds the list full is
+        // handled by its thread alone); (2) 16 lanes share each listed record and take its offset votes
+        // 16 apart, so the chain of dependent vote loads per lane is n_votes / 16 long instead of n_votes.
+        uint32_t *list = (uint32_t *)prod;
+        if (tid == 0) s_total = 0;
+        __syncthreads();
+        for (uint32_t i0 = h0; i0 < h1; i0 += CL_THREADS * 2) {        // (uniform trip count: the ballots need every lane)
+            int4 b0[2], b1[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                                   // two records' boxes in flight (64-VGPR budget)
+                const uint32_t i = min(i0 + j * CL_THREADS + tid, h1 - 1);
+                b0[j] = ((const int4 *)(box + i))[0]; b1[j] = ((const int4 *)(box + i))[1];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t i = i0 + j * CL_THREADS + tid, fc = (uint32_t)b1[j].w;
+                const bool keep = i < h1 && (fc & LF_OFF) && range_hits_span(b0[j].x, b0[j].w, org[0], RG) &&
+                                  range_hits_span(b0[j].y, b1[j].x, org[1], RG) && range_hits_span(b0[j].z, b1[j].y, org[2], RG);
+                const unsigned long long bal = __ballot(keep);             // one LDS atomic per wave, ranks from the ballot
+                uint32_t wb = 0;
+                if (lane == 0 && bal) wb = atomicAdd(&s_total, (uint32_t)__popcll(bal));
+                wb = __shfl(wb, 0);
+                if (keep) {
+                    const uint32_t slot = wb + (uint32_t)__popcll(bal & lanemask_lt());
+                    if (slot < CL_LIST) list[slot] = i;
+                    else cluster_add_votes(a, region, hits, box, i, 0u, 1u, org);   // list full: this thread takes the record alone
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t np = min(s_total, (uint32_t)CL_LIST);
+        for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) cluster_add_votes(a, region, hits, box, list[k >> 4], k & 15u, 16u, org);
+        __syncthreads();
+    } else if (a.leaf_hits) {
+        // Rotation votes depend only on the leaf (prediction.rs:601-636): the accumulator is
+        // sum over leaves of (times the leaf voted) x (its distinct cells), so the gather walks
+        // the leaves that voted at all instead of every hit -- u32 wrap-around makes
+        // hits * v * mult the same residue as that many separate adds.
+        const uint32_t *lh = a.leaf_hits + (size_t)frame * a.f.n_leaves;
+        uint32_t *list = (uint32_t *)prod;                    // same two-step scheme as the position gather
+        for (uint32_t c0 = l0; c0 < l1; c0 += CL_LIST) {
+            if (tid == 0) s_total = 0;
+            __syncthreads();
+            const uint32_t c1 = min(l1, c0 + CL_LIST);
+            for (uint32_t l0 = c0; l0 < c1; l0 += CL_THREADS) {          // (uniform trip count: the ballot needs every lane)
+                const uint32_t l = l0 + tid;
+                bool keep = false;
+                if (l < c1 && lh[l]) {
+                    const uint4 t2 = ((const uint4 *)(a.f.tpl + l))[2];
+                    const uint32_t bl = t2.y, bh = t2.z;
+                    keep = bl != 0xFFFFFFFFu && range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG) &&
+                           range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG) &&
+                           range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG);
+                }
+                const unsigned long long bal = __ballot(keep);             // one LDS atomic per wave, ranks from the ballot
+                uint32_t wb = 0;
+                if (lane == 0 && bal) wb = atomicAdd(&s_total, (uint32_t)__popcll(bal));
+                wb = __shfl(wb, 0);
+                if (keep) list[wb + (uint32_t)__popcll(bal & lanemask_lt())] = l;
+            }
+            __syncthreads();
+            const uint32_t np = s_total;
+            for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) {
+                const uint32_t l = list[k >> 4], sub = k & 15u;
+                const uint4 *tp = (const uint4 *)(a.f.tpl + l);
+                const uint4 t1 = tp[1], t2 = tp[2], t3 = tp[3];
+                const uint32_t v = lh[l] * t1.z, q1 = t2.w + (t3.x & 0xffffu);   // times the leaf voted x valtoadd
+                for (uint32_t q = t2.w + sub; q < q1; q += 16u) {
+                    const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                  // prediction.rs:635
+                    uint32_t dx = (b & 255u) - (uint32_t)org[0];
+                    uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
+                    uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
+                    if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        for (uint32_t i0 = h0; i0 < h1; i0 += CL_THREADS * 2) {
+            uint4 r[2];
+            uint32_t vv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t i = i0 + j * CL_THREADS + tid;
+                r[j].x = 0xFFFFFFFFu;
+                if (i < h1) { r[j] = *(const uint4 *)(hr + i); vv[j] = box[i].v; }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t bl = r[j].x, bh = r[j].y;
+                if (bl == 0xFFFFFFFFu) continue;
+                if (!range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG)) continue;
+                if (!range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG)) continue;
+                if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG)) continue;
+                const uint32_t v = vv[j];
+                for (uint32_t q = r[j].z; q < r[j].z + (r[j].w & 0xffffu); ++q) {
+                    const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                   // prediction.rs:635
+                    uint32_t dx = (b & 255u) - (uint32_t)org[0];
+                    uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
+                    uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
+                    if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
+    __shared__ uint32_t region[RG3];
+    __shared__ __attribute__((aligned(16))) float prod[CL_PROD_CAP * 4];
+    __shared__ uint32_t cnt[CL_CHUNKS * CL_WAVES];
+    __shared__ unsigned long long red64[CL_WAVES];
+    __shared__ uint32_t red32[CL_WAVES];
+    __shared__ int32_t s_pos[3];
+    __shared__ float s_acc[4];
+    __shared__ uint32_t s_total;
+
+    const int which = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+
+    const ClShared sh{region, prod, red64, red32, s_pos, &s_total};
+    cl_initial_guess(a, which, frame, sh);
+    __syncthreads();
+    int32_t pos[3] = {s_pos[0], s_pos[1], s_pos[2]};
+    if (a.dbg_guess && tid < 3) a.dbg_guess[(size_t)frame * 6 + which * 3 + tid] = pos[tid];
+    int32_t *trace = a.dbg_trace ? a.dbg_trace + ((size_t)which * a.n_frames + frame) * (a.iterations + 1) * 3 : nullptr;
+    if (trace && tid < 3) trace[tid] = pos[tid];
+
+    if (KNOB_STOP(a.stop == 1)) return;
+    // ---------------- mean shift (meanshift.rs:328-407)
+    uint32_t n_hits = a.hit_count[frame];
+    if (n_hits > a.hits_cap) n_hits = a.hits_cap;
+    int32_t org[3] = {0, 0, 0};     // region origin (cell coordinates of region[0])
+    bool have_region = false;
+    uint32_t steps = 0;
+    for (uint32_t it = 0; it < a.iterations; ++it) {
+        // window offset inside the region; the region is valid while 0 <= woff <= RG-20 on every axis
+        uint32_t wo0 = (uint32_t)pos[0] - 10u - (uint32_t)org[0], wo1 = (uint32_t)pos[1] - 10u - (uint32_t)org[1],
+                 wo2 = (uint32_t)pos[2] - 10u - (uint32_t)org[2];
+        if (!have_region || wo0 > RG - 20 || wo1 > RG - 20 || wo2 > RG - 20) {
+            // ---- (re)build the region centred on the window
+            for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)pos[k] - 10u - (uint32_t)((RG - 20) / 2));
+            wo0 = wo1 = wo2 = (RG - 20) / 2;
+            have_region = true;
+            __syncthreads();                       // previous iteration's readers are done
+            if (a.pre_region && it == 0 && n_hits >= a.pre_min_hits) {
+                // the region around the initial guess was gathered by k_region (several workgroups per frame)
+                const uint32_t *pr = a.pre_region + ((size_t)frame * 2 + which) * RG3;
+                for (int i = tid; i < RG3; i += CL_THREADS) region[i] = pr[i];
+            } else {
+                for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
+                __syncthreads();
+                cl_gather(a, which, frame, org, 0u, n_hits, 0u, a.f.n_leaves, sh);
+            }
+        }
+        __syncthreads();
+        if (KNOB_STOP(a.stop == 2)) return;
+        // ---- order-preserving compaction of the window's non-zero cells; window cell index
+        // (dx*20+dy)*20+dz = chunk*1024 + tid is the reference's summation order
+#pragma unroll 1
+        for (int c = 0; c < CL_CHUNKS; ++c) {
+            const uint32_t cell = (uint32_t)(c * CL_THREADS + tid);
+            uint32_t fv = 0;
+            if (cell < DH_GRID3) {
+                uint32_t dz = cell % 20u, dy = (cell / 20u) % 20u, dx = cell / 400u;
+                fv = region[((wo0 + dx) * RG + wo1 + dy) * RG + wo2 + dz];
+            }
+            uint64_t b = __ballot(fv != 0);
+            if (lane == 0) cnt[c * CL_WAVES + wave] = (uint32_t)__popcll(b);
+        }
+        __syncthreads();
+        if (wave == 0) {   // exclusive scan of the 128 (chunk, wave) counts, 2 per lane
+            uint32_t c0 = cnt[lane * 2], c1 = cnt[lane * 2 + 1];
+            uint32_t incl = c0 + c1;
+            for (int d = 1; d < WAVE; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            uint32_t ex = incl - (c0 + c1);
+            cnt[lane * 2] = ex; cnt[lane * 2 + 1] = ex + c0;
+            if (lane == WAVE - 1) s_total = incl;
+            if (lane < 4) s_acc[lane] = 0.0f;
+        }
+        __syncthreads();
+        const uint32_t total = s_total;
+        for (uint32_t base = 0; base < total; base += CL_PROD_CAP) {
+#pragma unroll 1
+            for (int c = 0; c < CL_CHUNKS; ++c) {
+                const uint32_t cell = (uint32_t)(c * CL_THREADS + tid);
+                const uint32_t dz = cell % 20u, dy = (cell / 20u) % 20u, dx = cell / 400u;
+                const uint32_t fv = cell < DH_GRID3 ? region[((wo0 + dx) * RG + wo1 + dy) * RG + wo2 + dz] : 0u;
+                uint64_t b = __ballot(fv != 0);
+                if (fv) {
+                    uint32_t k = cnt[c * CL_WAVES + wave] + (uint32_t)__popcll(b & lanemask_lt());
+                    // this sweep only parks (cell, value) in the cell's slot: no global load sits inside it
+                    if (k >= base && k < base + CL_PROD_CAP) *(uint2 *)(prod + (k - base) * 4) = make_uint2(cell, fv);
+                }
+            }
+            __syncthreads();
+            {   // one thread per parked cell: Gaussian weight (one global load, all in flight together) and products, in place
+                const uint32_t m = min((uint32_t)CL_PROD_CAP, total - base);
+                if ((uint32_t)tid < m) {
+                    const uint2 cf = *(const uint2 *)(prod + tid * 4);
+                    const uint32_t cell = cf.x, dz = cell % 20u, dy = (cell / 20u) % 20u, dx = cell / 400u;
+                    float w = __fmul_rn(a.kern_ord[cell], (float)cf.y);                     // meanshift.rs:370-379
+                    float ax = (float)(int32_t)((uint32_t)pos[0] + dx - 10u);               // :373-375
+                    float ay = (float)(int32_t)((uint32_t)pos[1] + dy - 10u);
+                    float az = (float)(int32_t)((uint32_t)pos[2] + dz - 10u);
+                    *(float4 *)(prod + tid * 4) = make_float4(__fmul_rn(ax, w), __fmul_rn(ay, w), __fmul_rn(az, w), w);
+                }
+            }
+            __syncthreads();
+            if (tid < 4) {   // the sequential chain: acc = acc + prod[i], in cell order
+                float acc = s_acc[tid];
+                uint32_t m = min((uint32_t)CL_PROD_CAP, total - base);
+                uint32_t i = 0;
+                for (; i + 8 <= m; i += 8) {
+                    float v0 = prod[(i + 0) * 4 + tid], v1 = prod[(i + 1) * 4 + tid], v2 = prod[(i + 2) * 4 + tid],
+                          v3 = prod[(i + 3) * 4 + tid], v4 = prod[(i + 4) * 4 + tid], v5 = prod[(i + 5) * 4 + tid],
+                          v6 = prod[(i + 6) * 4 + tid], v7 = prod[(i + 7) * 4 + tid];
+                    acc = __fadd_rn(acc, v0); acc = __fadd_rn(acc, v1); acc = __fadd_rn(acc, v2); acc = __fadd_rn(acc, v3);
+                    acc = __fadd_rn(acc, v4); acc = __fadd_rn(acc, v5); acc = __fadd_rn(acc, v6); acc = __fadd_rn(acc, v7);
+                }
+                for (; i < m; ++i) acc = __fadd_rn(acc, prod[i * 4 + tid]);
+                s_acc[tid] = acc;
+            }
+            __syncthreads();
+        }
+        if (KNOB_STOP(a.stop == 3)) return;
+        const float den = s_acc[3];
+        if (den == 0.0f) break;                                                              // :385-388
+        int32_t np0 = f32_as_i32(__fdiv_rn(s_acc[0], den)), np1 = f32_as_i32(__fdiv_rn(s_acc[1], den)),
+                np2 = f32_as_i32(__fdiv_rn(s_acc[2], den));                                   // :391-394
+        const bool fixed = np0 == pos[0] && np1 == pos[1] && np2 == pos[2];
+        pos[0] = np0; pos[1] = np1; pos[2] = np2;
+        steps++;
+        if (trace && tid < 3) trace[steps * 3 + tid] = pos[tid];
+        if (fixed) {
+            // a fixed point: every remaining iteration sees the same window and returns the same
+            // position, so the reference's result (and trace) is this position repeated
+            if (trace && tid < 3)
+                for (uint32_t s2 = steps + 1; s2 <= a.iterations; ++s2) trace[s2 * 3 + tid] = pos[tid];
+            steps = a.iterations;
+            break;
+        }
+    }
+    if (a.dbg_steps && tid == 0) a.dbg_steps[(size_t)which * a.n_frames + frame] = steps;
+    if (tid == 0) {
+        dh_pose *o = a.out + frame;
+        if (which == 0) {                                                                    // prediction.rs:486-488
+            o->mid_point[0] = (float)pos[0];
+            o->mid_point[1] = (float)pos[1];
+            o->mid_point[2] = (float)(int32_t)((uint32_t)pos[2] * (uint32_t)DH_ZSCALEFACTOR);
+            o->reserved = 0;
+        } else {                                                                             // :477-482
+            for (int k = 0; k < 3; ++k)
+                o->rotation[k] = __dmul_rn(__ddiv_rn(__dsub_rn((double)pos[k], 60.0), 60.0), 3.14159);
+        }
+    }
+}
+
+hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s) {
+    if (a.n_frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cluster, dim3(2, a.n_frames), dim3(CL_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+// ================================================================== k_region
+// The first region gather of k_cluster, spread over several workgroups per (frame, accumulator): with few frames in the
+// batch and many hit records per frame (large forests, stride 1-2: 60-90 k records per frame at BASELINE config 3) one
+// workgroup streaming a whole frame's records is the slowest thing in the step while most CUs idle.  Workgroup
+// (slice, frame, which) recomputes the initial guess (a few microseconds), gathers its share of the records (or leaves)
+// into an LDS region exactly as k_cluster would and adds its non-zero cells to the frame's pre-built region in global
+// memory (integer atomics: the sum over the slices is the region k_cluster would have built).
+__global__ void __launch_bounds__(CL_THREADS, 8) k_region(ClusterArgs a) {
+    __shared__ uint32_t region[RG3];
+    __shared__ __attribute__((aligned(16))) float prod[CL_PROD_CAP * 4];
+    __shared__ unsigned long long red64[CL_WAVES];
+    __shared__ uint32_t red32[CL_WAVES];
+    __shared__ int32_t s_pos[3];
+    __shared__ uint32_t s_total;
+    const int slice = blockIdx.x, frame = blockIdx.y, which = blockIdx.z, tid = threadIdx.x;
+    const ClShared sh{region, prod, red64, red32, s_pos, &s_total};
+    uint32_t n_hits = a.hit_count[frame];
+    if (n_hits > a.hits_cap) n_hits = a.hits_cap;
+    if (n_hits < a.pre_min_hits) return;                            // few records: k_cluster gathers this frame's regions itself
+    // this workgroup's share: hit records in whole rounds of the gather loops, leaves in whole list chunks
+    const uint32_t S = (uint32_t)a.pre_slices;
+    const uint32_t hper = ((n_hits + S - 1) / S + 2 * CL_THREADS - 1) / (2 * CL_THREADS) * (2 * CL_THREADS);
+    const uint32_t h0 = min(n_hits, (uint32_t)slice * hper), h1 = min(n_hits, h0 + hper);
+    const uint32_t lper = ((a.f.n_leaves + S - 1) / S + CL_LIST - 1) / CL_LIST * CL_LIST;
+    const uint32_t l0 = min(a.f.n_leaves, (uint32_t)slice * lper), l1 = min(a.f.n_leaves, l0 + lper);
+    const bool by_leaves = which == 1 && a.leaf_hits;
+    if (by_leaves ? l0 >= l1 : h0 >= h1) return;                    // nothing in this share (uniform for the workgroup)
+    cl_initial_guess(a, which, frame, sh);
+    __syncthreads();
+    int32_t org[3];
+    for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)s_pos[k] - 10u - (uint32_t)((RG - 20) / 2));
+    for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
+    __syncthreads();
+    cl_gather(a, which, frame, org, h0, h1, l0, l1, sh);
+    __syncthreads();
+    uint32_t *pr = a.pre_region + ((size_t)frame * 2 + which) * RG3;
+    for (int i = tid; i < RG3; i += CL_THREADS) {
+        const uint32_t v = region[i];
+        if (v) atomicAdd(&pr[i], v);
+    }
+}
+
+hipError_t dh_launch_region(const ClusterArgs &a, hipStream_t s) {
+    if (a.n_frames == 0 || a.iterations == 0 || !a.pre_region || a.pre_slices < 1) return hipSuccess;
+    if (a.n_frames > 65535) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(k_region, dim3(a.pre_slices, a.n_frames, 2), dim3(CL_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+// ================================================================== k_votes_dump (parity tap)
+// Emits every vote of one frame as an (x, y, z, value) record so a test can aggregate them into
+// the full sparse accumulator the reference builds (prediction.rs:635, :667).
+__global__ void __launch_bounds__(256) k_votes_dump(VotesDumpArgs a) {
+    uint32_t n = a.hit_count[a.frame];
+    if (n > a.hits_cap) n = a.hits_cap;
+    const HitRec *hits = a.hits + (size_t)a.frame * a.hits_cap;
+    const HitBox *box = a.hit_box + (size_t)a.frame * a.hits_cap;
+    const HitRot *hr = a.hit_rot + (size_t)a.frame * a.hits_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 rec = *(const float4 *)(hits + i);
+        const uint32_t v = box[i].v, fc = box[i].fc;
+        if (a.which == 0 && (fc & LF_OFF)) {
+            const uint32_t ob = __float_as_uint(rec.w);
+            for (uint32_t o = ob; o < ob + (fc >> 8); ++o) {
+                const float4 of = a.f.off4[o];
+                float nx = __fsub_rn(rec.x, of.x), ny = __fsub_rn(rec.y, of.y), nz = __fsub_rn(rec.z, of.z);
+                if (nz < 0.0f) continue;
+                uint32_t k = atomicAdd(a.count, 1u);
+                if (k < a.cap) {
+                    a.out[k * 4 + 0] = f32_as_i32(nx); a.out[k * 4 + 1] = f32_as_i32(ny);
+                    a.out[k * 4 + 2] = f32_as_i32(__fdiv_rn(nz, (float)DH_ZSCALEFACTOR)); a.out[k * 4 + 3] = (int32_t)v;
+                }
+            }
+        } else if (a.which == 1 && (fc & LF_ROT)) {
+            for (uint32_t r = hr[i].rb; r < hr[i].rb + (hr[i].n_rot & 0xffffu); ++r) {
+                uint32_t b = a.f.rot_bin[r];
+                uint32_t k = atomicAdd(a.count, 1u);
+                if (k < a.cap) {
+                    a.out[k * 4 + 0] = (int32_t)(b & 255u); a.out[k * 4 + 1] = (int32_t)((b >> 8) & 255u);
+                    a.out[k * 4 + 2] = (int32_t)((b >> 16) & 255u); a.out[k * 4 + 3] = (int32_t)(v * a.f.rot_mult[r]);
+                }
+            }
+        }
+    }
+}
+
+hipError_t dh_launch_votes_dump(const VotesDumpArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_votes_dump, dim3(256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

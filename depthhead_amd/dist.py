@@ -96,9 +96,10 @@ class ShardedPredictor:
     591-613 k at depth 2, 627-657 k at depth 4, no more beyond (`tools/experiments/pipeline_sweep.sh`).  Every step still processes one whole batch through every kernel.
 
     With `backend == "gloo"` (rehearsal on one device, or CPU-only hosts) the records are staged through host memory.
-    World size 1: no collective at all."""
+    World size 1: no collective at all -- unless `force_collective` (a process group of ONE rank still runs RCCL's
+    all-gather on device buffers: that is how the collective path is executed on a one-GPU box, `bench.py --force-dist`)."""
 
-    def __init__(self, hp, n_local: int, w: int, h: int, intrinsic, group=None, device=None):
+    def __init__(self, hp, n_local: int, w: int, h: int, intrinsic, group=None, device=None, force_collective: bool = False):
         import torch
         import torch.distributed as dist
         self.hps = list(hp) if isinstance(hp, (list, tuple)) else [hp]
@@ -108,14 +109,15 @@ class ShardedPredictor:
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.rank = self.dist.get_rank(group) if self.dist else 0
+        self.collective = self.dist is not None and (self.world > 1 or force_collective)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.on_device = self.dist is None or self.dist.get_backend(group) == "nccl"
         nb = n_local * POSE_BYTES
         # one pose / gather buffer pair per slot; with a single predictor two slots still alternate (gather i beside kernels i + 1)
-        self.slots = max(2, self.depth) if self.world > 1 else self.depth
+        self.slots = max(2, self.depth) if self.collective else self.depth
         self.pose_bufs = [torch.zeros(nb, dtype=torch.uint8, device=self.device) for _ in range(self.slots)]
         gdev = self.device if self.on_device else torch.device("cpu")
-        self.gathered = [torch.zeros(self.world * nb, dtype=torch.uint8, device=gdev) for _ in range(self.slots)] if self.world > 1 else None
+        self.gathered = [torch.zeros(self.world * nb, dtype=torch.uint8, device=gdev) for _ in range(self.slots)] if self.collective else None
         self.pending = [None] * self.slots
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.depth)] if self.depth > 1 else None
         self.count = 0
@@ -129,12 +131,17 @@ class ShardedPredictor:
         self.depth, self.hps, self.streams = 1, self.hps[:1], None
 
     def submit(self, frames_ptr: int, stream) -> int:
-        """Enqueue one step (`stream` is used at depth 1; deeper pipelines bring their own streams); returns the slot."""
+        """Enqueue one step; returns the slot.  At depth 1 the step runs on `stream`; deeper pipelines bring their own
+        streams, each of which first waits for the work already enqueued on `stream` (None: nothing to wait for)."""
         import torch
         b = 0 if self.graph else self.count % self.slots
         k = self.count % self.depth
         self.count += 1
         st = self.streams[k] if self.streams else stream
+        if self.streams and stream is not None:
+            # deeper pipelines launch on their own streams: whatever produced the frames on the caller's stream (an upload,
+            # `decode_depth_device`) has to be finished before k_boxsum reads them
+            st.wait_stream(stream)
         if self.pending[b] is not None:
             with torch.cuda.stream(st):                 # the stream that is about to overwrite the buffer waits for its last gather
                 self.pending[b].wait()
@@ -144,7 +151,7 @@ class ShardedPredictor:
         else:
             self.hps[k].predict_batch_device(frames_ptr, self.n_local, self.w, self.h, self.intrinsic, self.pose_bufs[b].data_ptr(),
                                              stream=st.cuda_stream)
-        if self.world > 1:
+        if self.collective:
             with torch.cuda.stream(st):                 # the collective (or the staging copy) orders itself after this step's kernels
                 src = self.pose_bufs[b] if self.on_device else self.pose_bufs[b].cpu()
                 self.pending[b] = self.dist.all_gather_into_tensor(self.gathered[b], src, group=self.group, async_op=True)
@@ -156,11 +163,11 @@ class ShardedPredictor:
             if self.pending[i] is not None:
                 self.pending[i].wait()
                 self.pending[i] = None
-        if self.world > 1:
+        if self.collective:
             self.dist.barrier(group=self.group)
         torch.cuda.synchronize(self.device)
 
     def last_poses(self) -> np.ndarray:
         """Gathered pose records (all ranks' shards in rank order) of the most recent step; call after fence()."""
         b = 0 if self.graph else (self.count - 1) % self.slots
-        return poses_from_bytes(self.gathered[b] if self.world > 1 else self.pose_bufs[b])
+        return poses_from_bytes(self.gathered[b] if self.collective else self.pose_bufs[b])

@@ -77,8 +77,21 @@ class EvaluationResult:
             self.res.append((person, entry))
 
     def to_json(self) -> str:
-        return json.dumps({"persons": list(self.persons), "trained_tree_path": self.trained_tree_path,
-                           "res": [[p, e.as_dict()] for p, e in self.res]})
+        """The file `eval_files/overview.html` loads.  serde_json writes `null` for a non-finite f32 / f64 (a pose component
+        can be inf when the frame's depth at the 2-D argmax is 0); Python's encoder would write a bare NaN / Infinity, which
+        `JSON.parse` rejects -- so non-finite values become null here too, and `allow_nan=False` makes a miss loud."""
+        def clean(x):
+            if isinstance(x, (list, tuple)):
+                return [clean(v) for v in x]
+            if isinstance(x, dict):
+                return {k: clean(v) for k, v in x.items()}
+            if isinstance(x, (float, np.floating)):
+                return float(x) if np.isfinite(x) else None
+            if isinstance(x, np.integer):
+                return int(x)
+            return x
+        return json.dumps(clean({"persons": list(self.persons), "trained_tree_path": self.trained_tree_path,
+                                 "res": [[p, e.as_dict()] for p, e in self.res]}), allow_nan=False)
 
     # ---- the report page's error definitions (overview.html) -------------------------------------------
     def _all(self, source: str):

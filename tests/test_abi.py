@@ -194,18 +194,20 @@ def test_product_code_never_touches_the_oracle():
 def test_product_library_has_no_profiling_knobs(hip_lib):
     """The kernel-truncating switches (DH_TRAV_STOP, ... -- "results invalid") are compiled only into the
     tools/ twin built with -DDH_PROFILING_KNOBS; the product library does not even contain their names, and
-    the environment is read in exactly one function (read_knobs, called by dh_predictor_create)."""
+    the environment is read in exactly one function (dh_read_knobs_ in dh_host.cpp, called by dh_predictor_create)."""
     blob = open(_lib.LIB_PATH, "rb").read()
     for name in (b"DH_TRAV_STOP", b"DH_EMIT_STOP", b"DH_VOTE_STOP", b"DH_CL_STOP", b"DH_TRAV_STAMPS"):
         assert name not in blob, name
     assert b"DH_FORCE_GENERAL" in blob     # (the result-preserving diagnostic switches are still there)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    api = open(os.path.join(root, "depthhead_amd", "csrc", "dh_api.hip")).read()
-    body = api[api.index("static Knobs read_knobs()"):]
+    csrc = os.path.join(root, "depthhead_amd", "csrc")
+    host = open(os.path.join(csrc, "dh_host.cpp")).read()
+    body = host[host.index("Knobs dh_read_knobs_()"):]
     body = body[:body.index("\n}\n") + 3]
-    assert api.count("getenv(") == body.count("getenv(") > 0, "getenv outside read_knobs()"
-    for fn in ("dh_kernels.hip", "dh_biwi.hip"):
-        assert "getenv(" not in open(os.path.join(root, "depthhead_amd", "csrc", fn)).read()
+    assert host.count("getenv(") == body.count("getenv(") > 0, "getenv outside dh_read_knobs_()"
+    for fn in sorted(os.listdir(csrc)):
+        if fn != "dh_host.cpp":
+            assert "getenv(" not in open(os.path.join(csrc, fn)).read(), fn
 
 
 def test_cpp_example_compiles_and_links(tmp_path):

@@ -1,0 +1,273 @@
+"""GPU tests added in round 3: the RCCL path executed on one GPU, an imported (serde-JSON) forest through the HIP path,
+the parity taps of chunked host batches, BASELINE configs[4] with its stated forest, concurrent predictors, and the
+exception containment of the C ABI.
+
+All comparisons are HIP path (through the C ABI) vs the CPU oracle, bit-exact.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from depthhead_amd import biwi, stamm_json, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hp_mod(hip_lib):
+    from depthhead_amd import prediction
+    return prediction
+
+
+def _poses_equal(a, ref):
+    return np.array_equal(a["mid_point"], ref["mid_point"]) and np.array_equal(a["rotation"], ref["rotation"])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+# ------------------------------------------------------------------ the RCCL gather, executed
+def test_rccl_all_gather_path_on_one_gpu(oracle, hip_lib, tmp_path):
+    """`bench.py --gpus 1 --force-dist` launched by torch.distributed.run with ONE rank: the process group is initialised
+    with the `nccl` backend (= RCCL on ROCm) on this box's GPU and every step goes through ShardedPredictor's asynchronous
+    `all_gather_into_tensor` on DEVICE buffers -- the code path the 8-GPU run takes (bench.py's init_process_group,
+    dist.py's collective, the MAX all-reduce of the timing, barrier, destroy).  The gathered poses of the last timed step
+    equal the oracle's.  A fresh child process, never an exec of this one."""
+    dump = str(tmp_path / "poses.npy")
+    nf, w, h, trees, depth = 12, 320, 240, 6, 10
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--frames", str(nf),
+           "--width", str(w), "--height", str(h), "--trees", str(trees), "--depth", str(depth), "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline", "--no-extras", "--dump-poses", dump]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["steps"] == 6 and out["value"] > 0
+    assert out["config"]["collective"].startswith("RCCL all_gather_into_tensor"), out["config"]
+    from depthhead_amd._lib import POSE_DTYPE
+    got = np.load(dump)
+    assert got.dtype == POSE_DTYPE and got.shape == (nf,)
+    forest = synth.fit_forest(trees, depth, synth.FOREST_SEED_BASE + 2)
+    model = synth.ModelParams(stepwidth=4)
+    K = synth.default_intrinsic(w, h)
+    frames = synth.biwi_batch(nf, w, h, first=0) if out["last_step_batch"] == "a" else np.roll(synth.biwi_batch(nf, w, h, first=10000), 7, axis=0)
+    assert _poses_equal(got, oracle.predict_batch(forest, model, frames, K))
+
+
+def test_predict_stream_over_rccl_world_of_one(oracle, hip_lib, tmp_path):
+    """dist.predict_stream / gather_poses with the `nccl` backend in a world of one rank (device buffers through RCCL)."""
+    script = tmp_path / "stream1.py"
+    script.write_text(f"""
+import os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch, torch.distributed as dist
+from depthhead_amd import synth
+from depthhead_amd.dist import predict_stream
+from depthhead_amd.prediction import HoughPrediction, IntrinsicMatrix
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+forest = synth.fit_forest(4, 8, synth.FOREST_SEED_BASE + 9, n_frames=8, subset=800)
+frames = synth.biwi_batch(7, 200, 160, first=70)
+with HoughPrediction(forest, synth.ModelParams(stepwidth=4)) as hp:
+    poses = predict_stream(hp, frames, IntrinsicMatrix(synth.default_intrinsic(200, 160)))
+np.save(sys.argv[1], poses)
+dist.barrier(); dist.destroy_process_group()
+""")
+    dump = str(tmp_path / "p.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(script), dump], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    forest = synth.fit_forest(4, 8, synth.FOREST_SEED_BASE + 9, n_frames=8, subset=800)
+    ref = oracle.predict_batch(forest, synth.ModelParams(stepwidth=4), synth.biwi_batch(7, 200, 160, first=70), synth.default_intrinsic(200, 160))
+    assert _poses_equal(np.load(dump), ref)
+
+
+# ------------------------------------------------------------------ an imported forest on the HIP path
+@pytest.mark.parametrize("one_child", ["right", "left"])
+def test_imported_serde_json_forest_through_the_hip_path(hp_mod, oracle, one_child):
+    """A fitted forest serialised to the serde-JSON shapes of prediction.rs:239-256 / houghforest.rs:63-78 / types.rs:33-37,
+    imported with an explicit `one_child`, run through the HIP path and compared with the oracle ON THE SAME IMPORTED
+    FOREST stage by stage (leaf ids, flags, grids, guesses, traces, pose).  The flipped convention is a different model:
+    its leaves differ.  PARITY UNPINNED for stamm's nesting and child convention (crate not vendored, Cargo.toml:17)."""
+    from test_gpu_parity import _check_frames
+    src = synth.fit_forest(5, 9, synth.FOREST_SEED_BASE + 31, n_frames=10, subset=1200)
+    params = synth.ModelParams(stepwidth=4, gaussian_sigma=7.5, meanshift_iterations=17)
+    text = stamm_json.export_json(src, params, one_child="right")          # the document says: Binar::One -> right
+    forest, model = stamm_json.import_json(text, one_child=one_child)
+    assert (model.stepwidth, model.gaussian_sigma, model.meanshift_iterations) == (4, 7.5, 17)
+    assert forest.n_nodes == src.n_nodes and forest.n_leaves == src.n_leaves
+    w, h = 320, 240
+    frames = synth.biwi_batch(3, w, h, first=820)
+    K = synth.default_intrinsic(w, h)
+    poses = _check_frames(hp_mod, oracle, forest, model, frames, K)
+    # against the forest the document was written from: same model under "right" (renumbered nodes / leaves), another under "left"
+    ref_src = oracle.predict_batch(src, params, frames, K)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.debug_enable(True)
+        hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        leaf = hp.debug_leaf_indices(3, w, h)
+    with hp_mod.HoughPrediction(src, params, device=0) as hp:
+        hp.debug_enable(True)
+        hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        leaf_src = hp.debug_leaf_indices(3, w, h)
+    walked = leaf_src >= 0
+    same_leaf_payload = np.array_equal(forest.leaf_prob[leaf[walked]], src.leaf_prob[leaf_src[walked]])
+    if one_child == "right":
+        assert _poses_equal(poses, ref_src) and same_leaf_payload
+    else:
+        assert not same_leaf_payload                                          # the flipped convention walks to other leaves
+
+
+# ------------------------------------------------------------------ taps of a chunked host batch
+def test_taps_of_a_host_batch_larger_than_one_upload_chunk(hp_mod, oracle):
+    """With the taps on, a host batch is ONE device batch whatever its size (round 2 split 40 frames into 20 + 20 and the
+    taps then described the second half under the first frames' indices): 40 frames, every stage against the oracle."""
+    from test_gpu_parity import _check_frames
+    forest = synth.fit_forest(4, 8, synth.FOREST_SEED_BASE + 9, n_frames=8, subset=800)
+    frames = synth.biwi_batch(40, 160, 120, first=1200)
+    _check_frames(hp_mod, oracle, forest, synth.ModelParams(stepwidth=6), frames, synth.default_intrinsic(160, 120), full=False)
+    # product mode (taps off): the same call is chunked (16 + 24, ...) and gives the same poses; the grid / hit-count taps
+    # then describe the last chunk only (include/depthhead_hip.h)
+    os.environ["DH_STAGE_CHUNK"] = "16"
+    try:
+        with hp_mod.HoughPrediction(forest, synth.ModelParams(stepwidth=6), device=0) as hp:
+            a = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(synth.default_intrinsic(160, 120)))
+    finally:
+        os.environ.pop("DH_STAGE_CHUNK", None)
+    assert _poses_equal(a, oracle.predict_batch(forest, synth.ModelParams(stepwidth=6), frames, synth.default_intrinsic(160, 120)))
+
+
+# ------------------------------------------------------------------ BASELINE configs[4] with its stated forest
+@pytest.fixture(scope="module")
+def c5_forests():
+    return {"synth": synth.synth_forest(10, 15, synth.FOREST_SEED_BASE + 2), "fitted": synth.fit_forest(10, 15, synth.FOREST_SEED_BASE + 2)}
+
+
+@pytest.mark.parametrize("kind", ["synth", "fitted"])
+def test_config5_stated_forest_stagewise(hp_mod, oracle, c5_forests, kind):
+    """320x240 frames, stride 1 (38 400 windows), the 10-tree depth-15 forest -- `synth_forest(10, 15)`
+    as BASELINE.md section 4 states it, and the fitted one the bench uses.  Four frames stage by stage vs the oracle."""
+    from test_gpu_parity import _check_frames
+    frames = synth.biwi_batch(4, 320, 240, first=30)
+    _check_frames(hp_mod, oracle, c5_forests[kind], synth.ModelParams(stepwidth=1), frames, synth.default_intrinsic(320, 240), full=False)
+
+
+@pytest.mark.parametrize("kind", ["synth", "fitted"])
+def test_config5_stated_forest_graph_replay_64_frames(hp_mod, oracle, c5_forests, kind):
+    """... and the per-GPU form of configs[4]: a 64-frame batch captured once into a hipGraph and replayed (second replay on
+    other frames written into the same buffer), poses vs oracle.predict_batch."""
+    torch = pytest.importorskip("torch")
+    w, h, n = 320, 240, 64
+    forest, model = c5_forests[kind], synth.ModelParams(stepwidth=1)
+    K = synth.default_intrinsic(w, h)
+    a_np, b_np = synth.biwi_batch(n, w, h, first=0), synth.biwi_batch(n, w, h, first=500)
+    dev = torch.device("cuda", 0)
+    buf = torch.from_numpy(a_np.view(np.int16)).to(dev)
+    out = torch.zeros(n * 40, dtype=torch.uint8, device=dev)
+    from depthhead_amd._lib import POSE_DTYPE
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.reserve(n, w, h)
+        hp.graph_capture(buf.data_ptr(), n, w, h, hp_mod.IntrinsicMatrix(K), out.data_ptr())
+        st = torch.cuda.current_stream(dev)
+        hp.graph_launch(st.cuda_stream)
+        torch.cuda.synchronize()
+        pa = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE).copy()
+        buf.copy_(torch.from_numpy(b_np.view(np.int16)))
+        hp.graph_launch(st.cuda_stream)
+        torch.cuda.synchronize()
+        pb = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE).copy()
+    assert _poses_equal(pa, oracle.predict_batch(forest, model, a_np, K))
+    assert _poses_equal(pb, oracle.predict_batch(forest, model, b_np, K))
+
+
+# ------------------------------------------------------------------ concurrent predictors (include/depthhead_hip.h: "may run concurrently")
+def test_concurrent_predictors_keep_their_poses(hp_mod, oracle):
+    """Host threads, each with its own predictor, mixing the host entry points (pageable frames of changing batch sizes --
+    workspaces grow beside other predictors' running kernels --, run-length coded payloads, predict_mask, guesses); every
+    result is compared with a single-threaded reference pass.  One deterministic sequence per thread (tools/soak_threads.py
+    is the long form of this)."""
+    w, h = 320, 240
+    forest = synth.fit_forest(6, 10, synth.FOREST_SEED_BASE + 81, n_frames=12, subset=1500)
+    model = synth.ModelParams(stepwidth=3)
+    frames = synth.biwi_batch(30, w, h, first=900)
+    intr = hp_mod.IntrinsicMatrix(synth.default_intrinsic(w, h))
+    pay = [biwi.encode_depth(f) for f in frames]
+    rs0 = np.random.RandomState(5)
+    midp = rs0.uniform(-200, 1200, (30, 3)).astype(np.float32)
+    rot = rs0.uniform(-1, 1, (30, 3))
+    with hp_mod.HoughPrediction(forest, model) as hp0:
+        ref = hp0.predict_batch(frames, intr).copy()
+        refg = hp0.predict_batch(frames, intr, midp, rot).copy()
+        rmask = hp0.predict_mask(frames[:3]).copy()
+    assert _poses_equal(ref[:8], oracle.predict_batch(forest, model, frames[:8], synth.default_intrinsic(w, h)))
+    errs = []
+
+    def work(t):
+        try:
+            rs = np.random.RandomState(100 + t)
+            with hp_mod.HoughPrediction(forest, model) as hp:
+                for it in range(18):
+                    idx = rs.randint(0, 30, int(rs.randint(1, 31)))
+                    k = (it + t) % 4
+                    if k == 0:
+                        out, want = hp.predict_batch(frames[idx].copy(), intr), ref[idx]
+                    elif k == 1:
+                        out, want = hp.predict_batch_rle([pay[i] for i in idx], intr), ref[idx]
+                    elif k == 2:
+                        out, want = hp.predict_batch(frames[idx].copy(), intr, midp[idx], rot[idx]), refg[idx]
+                    else:
+                        if not np.array_equal(hp.predict_mask(frames[:3]), rmask):
+                            errs.append((t, it, "predict_mask"))
+                        continue
+                    if not _poses_equal(out, want):
+                        errs.append((t, it, k, len(idx)))
+        except Exception as e:   # noqa
+            errs.append((t, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+
+
+# ------------------------------------------------------------------ nothing throws across the ABI
+def test_bad_payload_batches_come_back_as_error_codes(hp_mod, hip_lib):
+    """Every `extern "C"` entry point runs inside dh_guard_ (dh_host.h; the guard itself -- bad_alloc, std::exception, anything
+    else -> an error code -- is exercised under the sanitizers by tests/host/host_check.cpp).  Here, through the real library:
+    malformed batches are error codes with the frame named, and the predictor stays usable afterwards."""
+    import ctypes as C
+    from depthhead_amd._lib import DepthheadError
+    forest = synth.fit_forest(4, 8, synth.FOREST_SEED_BASE + 9, n_frames=8, subset=800)
+    with hp_mod.HoughPrediction(forest, synth.ModelParams(stepwidth=4), device=0) as hp:
+        good = biwi.encode_depth(synth.biwi_like(96, 96, 5))
+        buf = np.frombuffer(good, dtype=np.uint8)
+        n = 3
+        ptrs = (C.c_void_p * n)(*([buf.ctypes.data] * n))
+        lens = (C.c_size_t * n)(*([buf.size] * n))
+        w_, h_ = C.c_uint32(), C.c_uint32()
+        assert hip_lib.dh_biwi_decode_depth_device(hp._ph, ptrs, lens, C.c_int(n), None, C.c_size_t(0), C.byref(w_), C.byref(h_)) == 0
+        assert (w_.value, h_.value) == (96, 96)
+        # a NULL payload inside the batch
+        ptrs2 = (C.c_void_p * n)(buf.ctypes.data, None, buf.ctypes.data)
+        rc = hip_lib.dh_biwi_decode_depth_device(hp._ph, ptrs2, lens, C.c_int(n), None, C.c_size_t(0), C.byref(w_), C.byref(h_))
+        assert rc == -1 and b"frame 1" in hip_lib.dh_last_error()
+        with pytest.raises(DepthheadError):
+            hp.predict_batch_rle([good, good[:11]], hp_mod.IntrinsicMatrix(synth.default_intrinsic(96, 96)))
+        # the predictor is still usable
+        out = hp.predict_batch_rle([good], hp_mod.IntrinsicMatrix(synth.default_intrinsic(96, 96)))
+        assert out.shape == (1,)
