@@ -38,11 +38,8 @@ python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, hashlib, json, os, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(out)
-def kernel_hash():
-    h = hashlib.sha256()
-    for fn in ("dh_kernels.hip", "dh_api.hip", "dh_internal.h"):
-        h.update(open(os.path.join(root, "depthhead_amd", "csrc", fn), "rb").read())
-    return h.hexdigest()[:16]
+sys.path.insert(0, root)
+from bench import kernel_source_hash as kernel_hash      # the same hash bench.py checks a profile against
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{out}/{tag}_pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
