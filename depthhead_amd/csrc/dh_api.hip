@@ -116,7 +116,8 @@ struct dh_predictor {
     size_t tile_list_stride = 0;    // entries per x
     unsigned long long *box_mask = nullptr;   // [cap][ceil(box_rows / 32)][box_parts] which lanes wrote non-zero sums last time (BoxArgs::blk_mask)
     uint32_t *win_patch = nullptr;   // [cap][win_cap] window list: position in the window grid
-    int32_t *win_leaf = nullptr;     // [cap][T][win_cap] window list: leaf per tree
+    uint8_t *win_leaf = nullptr;     // [cap][T][win_cap] window list: leaf per tree (u16 entries for forests of <= 65 535 leaves, else i32)
+    int leaf_ls = 2;                 // log2 of its entry size
     uint32_t *leaf_hits = nullptr;   // [cap][n_leaves] rotation-vote histogram (inside `counters`), only for forests of <= DH_LEAF_HIST_MAX leaves
     size_t zero_words = 0;           // words of `counters` zeroed before every batch
     uint32_t hits_cap = 0;
@@ -432,13 +433,17 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     // several workgroups: worth it from ~8 k hit records per frame on the rotation-record path of large forests, from
     // ~65 k with the leaf histogram (measured: config 3 cluster 0.77 -> 0.34 ms; config 5, 38 k records per frame, would lose)
     p->pre_min_hits = p->knobs.region_min_hits > 0 ? (uint32_t)p->knobs.region_min_hits : (leaf_hist ? 65536u : 8192u);
-    if (!p->knobs.no_region && hits_cap >= 4 * (size_t)p->pre_min_hits) {   // (a frame of this geometry can hold that many records at all)
+    // (only where a frame of this geometry can plausibly hold that many records: a few per cent of its (window, tree) pairs vote)
+    if (!p->knobs.no_region && hits_cap >= (leaf_hist ? 8 : 4) * (size_t)p->pre_min_hits) {
         // k_region serves batches of up to 128 frames (beyond that the (frame, accumulator) workgroups of k_cluster fill the chip themselves)
         p->pre_cap = std::min(cap, 128);
         STEP(dev_alloc(p, &p->pre_region, (size_t)p->pre_cap * 2 * DH_REGION_CELLS));
+        // zeroed once: k_cluster leaves every pre-gathered region it consumes zero again, so there is no per-batch fill
+        if (rc == DH_OK && hipMemsetAsync(p->pre_region, 0, (size_t)p->pre_cap * 2 * DH_REGION_CELLS * sizeof(uint32_t), p->own_stream) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(pre_region)");
     }
     STEP(dev_alloc(p, &p->win_patch, (size_t)cap * std::max(g.win_cap, 1)));
-    STEP(dev_alloc(p, &p->win_leaf, (size_t)cap * std::max(g.win_cap, 1) * p->n_trees));
+    p->leaf_ls = p->n_leaves <= 65535u ? 1 : 2;
+    STEP(dev_alloc(p, &p->win_leaf, ((size_t)cap * std::max(g.win_cap, 1) * p->n_trees) << p->leaf_ls));
     if (!p->knobs.no_tile_list && g.npatch > 0) {
         p->tile_list_stride = (size_t)((cap + 7) / 8) * g.tiles_x * g.tiles_y;
         if (p->tile_list_stride < ((size_t)1 << 31)) STEP(dev_alloc(p, &p->tile_list, (size_t)DH_MAX_CHUNKS * 8 * (p->tile_list_stride + 1)));
@@ -545,6 +550,8 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     }
     // product mode: the flagged tiles as compact lists, so that the workgroups of empty tiles sit at the end of k_traverse's grid
     // (with the taps on, every tile position keeps its workgroup: those of empty tiles write the taps' "background")
+    // (also for a single frame: skipping the list's launch was measured in round 3 and k_traverse alone got 10 us slower than
+    // the 5 us the list costs -- profiles/r03_single_frame.md)
     const bool use_list = p->tile_list && g.npatch > 0 && !leaf_out && !flags_out && !p->debug;
     uint32_t *tl_list = use_list ? p->tile_list + (size_t)chunk * 8 * (p->tile_list_stride + 1) : nullptr;
     uint32_t *tl_count = use_list ? tl_list + 8 * p->tile_list_stride : nullptr;
@@ -578,7 +585,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         const int tiles = g.tiles_x * g.tiles_y;
         uint32_t *win_count = p->counters + (size_t)p->cap_frames * (1 + DH_POSGRID + DH_GRID3 + (size_t)g.flag_words) + (size_t)f0 * tiles;
         ta.win_count = win_count; ta.win_cap = g.win_cap;
-        ta.win_patch = p->win_patch + (size_t)f0 * g.win_cap; ta.win_leaf = p->win_leaf + (size_t)f0 * g.win_cap * p->n_trees;
+        ta.win_patch = p->win_patch + (size_t)f0 * g.win_cap; ta.win_leaf = p->win_leaf + (((size_t)f0 * g.win_cap * p->n_trees) << p->leaf_ls); ta.leaf_ls = p->leaf_ls;
         ta.dbg_leaf = leaf_out ? leaf_out : p->debug ? p->dbg_leaf + (size_t)f0 * g.npatch * p->n_trees : nullptr;
         ta.dbg_flags = flags_out ? flags_out : p->debug ? p->dbg_flags + (size_t)f0 * g.npatch : nullptr;
         if (use_list) { ta.tile_list = tl_list; ta.tile_list_count = tl_count; ta.tile_list_stride = (uint32_t)p->tile_list_stride; }
@@ -591,7 +598,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
             ea.px = g.px; ea.py = g.py; ea.tiles = tiles;
             memcpy(ea.kinv, kinv, 9 * sizeof(float));
             ea.f = p->dev;
-            ea.win_count = win_count; ea.win_patch = ta.win_patch; ea.win_leaf = ta.win_leaf; ea.win_cap = g.win_cap;
+            ea.win_count = win_count; ea.win_patch = ta.win_patch; ea.win_leaf = ta.win_leaf; ea.leaf_ls = p->leaf_ls; ea.win_cap = g.win_cap;
             ea.hits = p->hits + hoff; ea.hit_box = p->hit_box + hoff; ea.hit_rot = p->hit_rot + hoff;
             ea.hit_count = hit_count; ea.hits_cap = p->hits_cap;
             ea.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
@@ -641,8 +648,6 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
             ca.pre_region = p->pre_region + (size_t)f0 * 2 * DH_REGION_CELLS;
             ca.pre_slices = slices;
             ca.pre_min_hits = p->pre_min_hits;
-            if (p->capturing) HIP_TRY(dh_launch_zero(ca.pre_region, (size_t)n * 2 * DH_REGION_CELLS * sizeof(uint32_t), s));
-            else HIP_TRY(hipMemsetAsync(ca.pre_region, 0, (size_t)n * 2 * DH_REGION_CELLS * sizeof(uint32_t), s));
             HIP_TRY(dh_launch_region(ca, s));
         }
         HIP_TRY(dh_launch_cluster(ca, s));

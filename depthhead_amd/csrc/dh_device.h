@@ -93,3 +93,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
     return v;
 }
+
+// Window list entries (leaf reached per (tree, active window)): 16-bit when the forest has at most 65 535 leaves -- half the
+// bytes k_traverse writes and k_emit reads back -- else 32-bit.  `ls` = log2 of the entry size.
+__device__ __forceinline__ void store_leaf(char *base, int ls, int idx, int32_t leaf) {
+    if (ls == 1) ((uint16_t *)base)[idx] = (uint16_t)leaf;
+    else ((int32_t *)base)[idx] = leaf;
+}
+__device__ __forceinline__ uint32_t load_leaf(const char *base, int ls, size_t idx) {
+    return ls == 1 ? (uint32_t)((const uint16_t *)base)[idx] : (uint32_t)((const int32_t *)base)[idx];
+}

@@ -286,10 +286,11 @@ int dh_choose_tile_(const TileQuery &p, Geom &g) {
         while (g.top_levels > 0 && (size_t)p.n_trees * (1u << g.top_levels) * 12 > 48 * 1024) --g.top_levels;
     }
     const int top_words = g.uniform && p.absorb_ok ? (int)p.n_trees * (1 << g.top_levels) * 3 : 0;
+    const long max_win = 1024;      // one thread per window position in the gate
     long best = -1;
     for (int py = 1; py <= std::min(g.ny, 64); ++py)
         for (int px = 1; px <= std::min(g.nx, 64); ++px) {
-            if (px * py > 1024) continue;
+            if (px * py > max_win) continue;
             if (fx > 0 && fy > 0 && (px != std::min(fx, g.nx) || py != std::min(fy, g.ny))) continue;
             // uniform path: tiles start on 16-byte boundaries of the box image's planes (direct-to-LDS copy)
             if (rw > 0 && (px & 3) != 0 && px < g.nx && !(fx > 0)) continue;

@@ -115,7 +115,8 @@ struct TraverseArgs {
     // window list (read by k_emit): tile t owns slots [t * px * py, t * px * py + win_count[frame][t])
     uint32_t *win_count;    // [n_frames][tiles] active windows per tile (zeroed per batch by the host)
     uint32_t *win_patch;    // [n_frames][win_cap] position of the window in the frame's window grid
-    int32_t  *win_leaf;     // [n_frames][T][win_cap] leaf reached in every tree
+    void     *win_leaf;     // [n_frames][T][win_cap] leaf reached in every tree: u16 entries when leaf_ls == 1 (forests of <= 65 535 leaves), else i32
+    int       leaf_ls;      // log2 of the entry size of win_leaf (1 or 2)
     int       win_cap;      // tiles * px * py
     int32_t  *dbg_leaf;     // nullable [n][npatch][T]
     uint8_t  *dbg_flags;    // nullable [n][npatch]
@@ -132,7 +133,8 @@ struct EmitArgs {
     DevForest f;
     const uint32_t *win_count;
     const uint32_t *win_patch;
-    const int32_t  *win_leaf;
+    const void     *win_leaf;   // see TraverseArgs
+    int       leaf_ls;
     int       win_cap;
     HitRec   *hits;
     HitBox   *hit_box;

@@ -220,6 +220,9 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
             __syncthreads();
         }
     } else {
+        // (forests without a leaf histogram: every thread takes its own records' rotation cells.  The two-step survivor list
+        // of the position gather was tried here in round 3 and lost: 0.130 vs 0.119 ms on the 35 k-leaf forest -- a record has
+        // at most a few dozen distinct cells, and the loads of a thread's loop are independent.)
         for (uint32_t i0 = h0; i0 < h1; i0 += CL_THREADS * 2) {
             uint4 r[2];
             uint32_t vv[2];
@@ -288,8 +291,9 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             __syncthreads();                       // previous iteration's readers are done
             if (a.pre_region && it == 0 && n_hits >= a.pre_min_hits) {
                 // the region around the initial guess was gathered by k_region (several workgroups per frame)
-                const uint32_t *pr = a.pre_region + ((size_t)frame * 2 + which) * RG3;
-                for (int i = tid; i < RG3; i += CL_THREADS) region[i] = pr[i];
+                // (consumed and left zero again: the pre-gathered regions need no per-batch fill)
+                uint32_t *pr = a.pre_region + ((size_t)frame * 2 + which) * RG3;
+                for (int i = tid; i < RG3; i += CL_THREADS) { const uint32_t v = pr[i]; region[i] = v; if (v) pr[i] = 0; }
             } else {
                 for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
                 __syncthreads();

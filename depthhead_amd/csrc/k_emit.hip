@@ -13,7 +13,7 @@
 #define EMIT_THREADS 256
 // EB = trees handled per batch of gathers: the smallest instance that holds all T trees keeps the registers (and with them the
 // occupancy of this latency-bound kernel) in proportion to the forest: 62 VGPRs at EB = 8, 80 at 10, 122 at 16.
-template <int EB>
+template <int EB, int LS>      // LS: log2 of the window list's leaf entry size (dh_device.h: load_leaf)
 __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
     const int frame = blockIdx.y, lane = threadIdx.x & (WAVE - 1);
     const int pp = a.px * a.py;
@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
     const size_t w = (size_t)tile * pp + slot;                           // slot in the frame's window list
     uint32_t cnt = 0, gp = 0;
     bool gated = false;
-    const int32_t *wl = a.win_leaf + (size_t)frame * a.win_cap * T + w;
+    constexpr int ls = LS;
+    const char *wl = (const char *)a.win_leaf + (((size_t)frame * a.win_cap * T + w) << ls);
     unsigned long long voting = 0;          // bit t: the leaf reached in tree t casts votes (T <= 64; else recomputed below)
     uint32_t rotv = 0, l[EB];       // bit k: leaf l[k] casts rotation votes and the window passed the gate
 #pragma unroll
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
             double pr[EB];
             uint4 g[EB];
 #pragma unroll
-            for (int k = 0; k < EB; ++k) l[k] = (uint32_t)wl[(size_t)min(t0 + k, T - 1) * a.win_cap];
+            for (int k = 0; k < EB; ++k) l[k] = load_leaf(wl, ls, (size_t)min(t0 + k, T - 1) * a.win_cap);
             if (t0 == 0) {
                 // window centre (for prediction.rs:551-554), requested now: its latency hides behind the batch
                 const int gyi = (int)(gp / (uint32_t)a.nx), gxi = (int)gp - gyi * a.nx;
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
     HitRec *dst = a.hits + (size_t)frame * a.hits_cap;
     HitBox *dbox = a.hit_box + (size_t)frame * a.hits_cap;
     HitRot *drot = a.hit_rot + (size_t)frame * a.hits_cap;
-    const int32_t *wlf = a.win_leaf + (size_t)frame * a.win_cap * T;
+    const char *wlf = (const char *)a.win_leaf + (((size_t)frame * a.win_cap * T) << ls);
     const int wi = (int)w;
     // One LANE per hit record: hit h of the wave belongs to the voting window (lane) s with
     // excl_s <= h < excl_s + cnt_s and is its (h - excl_s)-th voting tree.  Every lane finds its (s, tree)
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
                 if (h < ex || h >= ex + cn) continue;
                 uint32_t r = ex;
                 for (int t = 0; t < T; ++t) {
-                    const uint32_t lf = a.f.leaf_flags[(uint32_t)wlf[(size_t)t * a.win_cap + sw]];
+                    const uint32_t lf = a.f.leaf_flags[load_leaf(wlf, ls, (size_t)t * a.win_cap + sw)];
                     if ((lf & LF_PROB) && (lf & (LF_ROT | LF_OFF))) { if (r == h) { src = sl; tree = t; } ++r; }
                 }
             }
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
         const float p0 = __shfl(q0, src), p1 = __shfl(q1, src), p2 = __shfl(q2, src);
         const uint32_t o = base + h;
         if (h < wave_total && o < a.hits_cap) {
-            const uint32_t lid = (uint32_t)wlf[(size_t)tree * a.win_cap + sw];
+            const uint32_t lid = load_leaf(wlf, ls, (size_t)tree * a.win_cap + sw);
             const uint4 *tp = (const uint4 *)(a.f.tpl + lid);
             const uint4 t0 = tp[0], t1 = tp[1], t2v = tp[2], t3 = tp[3];
             const float mn0 = __uint_as_float(t0.x), mn1 = __uint_as_float(t0.y), mn2 = __uint_as_float(t0.z),
@@ -195,10 +196,16 @@ hipError_t dh_launch_emit(const EmitArgs &a, hipStream_t s) {
     if (a.n_frames > 65535) return hipErrorInvalidConfiguration;
     const dim3 grid((a.npatch + EMIT_THREADS - 1) / EMIT_THREADS, a.n_frames), block(EMIT_THREADS);
     const uint32_t T = a.f.n_trees;
-    if (T <= 4) hipLaunchKernelGGL(k_emit<4>, grid, block, 0, s, a);
-    else if (T <= 8) hipLaunchKernelGGL(k_emit<8>, grid, block, 0, s, a);
-    else if (T <= 10) hipLaunchKernelGGL(k_emit<10>, grid, block, 0, s, a);
-    else if (T <= 12) hipLaunchKernelGGL(k_emit<12>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(k_emit<16>, grid, block, 0, s, a);
+#define EMIT_LAUNCH(EB_)                                                                       \
+    do {                                                                                       \
+        if (a.leaf_ls == 1) hipLaunchKernelGGL((k_emit<EB_, 1>), grid, block, 0, s, a);        \
+        else hipLaunchKernelGGL((k_emit<EB_, 2>), grid, block, 0, s, a);                       \
+    } while (0)
+    if (T <= 4) EMIT_LAUNCH(4);
+    else if (T <= 8) EMIT_LAUNCH(8);
+    else if (T <= 10) EMIT_LAUNCH(10);
+    else if (T <= 12) EMIT_LAUNCH(12);
+    else EMIT_LAUNCH(16);
+#undef EMIT_LAUNCH
     return hipGetLastError();
 }

@@ -263,7 +263,7 @@ __device__ __forceinline__ bool sat_passes(uint32_t *sat, uint32_t *flag, const 
 // (houghforest.rs:185-193) on two rectangle sums with the integer test of NodeU, falling back to
 // the reference's own f64 arithmetic inside the band the integer test cannot decide.
 template <int W>
-__device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32_t *sat, int32_t *wleaf, int32_t *dleaf, const uint32_t *active,
+__device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32_t *sat, char *wleaf, int32_t *dleaf, const uint32_t *active,
                                              const uint32_t *agp, int n_active, int total, int cx, int ss, int T) {
     const int tid = threadIdx.x;
     const NodeU *nodes_u = (const NodeU *)a.nodes_u;
@@ -310,7 +310,7 @@ __device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32
 #pragma unroll
         for (int i = 0; i < W; ++i)
             if (k0 + i * TRAV_THREADS < total) {
-                wleaf[dst[i]] = ~cur[i];
+                store_leaf(wleaf, a.leaf_ls, dst[i], ~cur[i]);
                 if (dleaf) dleaf[ddst[i]] = ~cur[i];
             }
     }
@@ -329,7 +329,7 @@ __device__ __forceinline__ void walk_uniform(const TraverseArgs &a, const uint32
 //  * a walk that lands in the ambiguity band of a node leaves the loop with that node's code, is decided by the reference's
 //    f64 arithmetic and re-enters (rare; the layout is described at k_nodes_compact).
 template <int W>
-__device__ __forceinline__ void walk_absorb(const TraverseArgs &a, const uint32_t *sat, const uint32_t *top, int32_t *wleaf, int32_t *dleaf,
+__device__ __forceinline__ void walk_absorb(const TraverseArgs &a, const uint32_t *sat, const uint32_t *top, char *wleaf, int32_t *dleaf,
                                             const uint32_t *active, const uint32_t *agp, int n_active, int total, int cx, int ss, int T) {
     const int tid = threadIdx.x;
     const char *tab = (const char *)a.nodes_a;
@@ -417,7 +417,7 @@ __device__ __forceinline__ void walk_absorb(const TraverseArgs &a, const uint32_
         for (int i = 0; i < W; ++i)
             if (k0 + i * TRAV_THREADS < total) {
                 const int32_t leaf = (int32_t)((cur[i] - lb) >> 4);
-                wleaf[dst[i]] = leaf;
+                store_leaf(wleaf, a.leaf_ls, dst[i], leaf);
                 if (dleaf) dleaf[ddst[i]] = leaf;
             }
     }
@@ -433,7 +433,7 @@ __device__ __forceinline__ void walk_absorb(const TraverseArgs &a, const uint32_
 // Root-to-leaf walks of the general path with the integer split test of NodeG (see k_traverse), W walks per lane in lock
 // step like walk_uniform.  sat is the tile's summed-area table modulo 2^32 with row stride ss.
 template <int W>
-__device__ __forceinline__ void walk_general_int(const TraverseArgs &a, const uint32_t *sat, int32_t *wleaf, int32_t *dleaf, const uint32_t *active,
+__device__ __forceinline__ void walk_general_int(const TraverseArgs &a, const uint32_t *sat, char *wleaf, int32_t *dleaf, const uint32_t *active,
                                                  const uint32_t *agp, int n_active, int total, int cx, int ss, int T) {
     const int tid = threadIdx.x;
     const NodeG *nodes_g = (const NodeG *)a.nodes_g;
@@ -495,7 +495,7 @@ __device__ __forceinline__ void walk_general_int(const TraverseArgs &a, const ui
 #pragma unroll
         for (int i = 0; i < W; ++i)
             if (k0 + i * TRAV_THREADS < total) {
-                wleaf[dst[i]] = ~cur[i];
+                store_leaf(wleaf, a.leaf_ls, dst[i], ~cur[i]);
                 if (dleaf) dleaf[ddst[i]] = ~cur[i];
             }
     }
@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
     // tile area under a slower loop; as an 8-byte-per-slot implicit heap it is what walk_absorb uses now.)
     // Trees are validated acyclic on the host, so every walk ends.
     const int total = n_active * T;
-    int32_t *wleaf = a.win_leaf + (size_t)frame * a.win_cap * T + wbase;                     // [tree][win_cap] per frame
+    char *wleaf = (char *)a.win_leaf + (((size_t)frame * a.win_cap * T + wbase) << a.leaf_ls);   // [tree][win_cap] per frame
     int32_t *dleaf = a.dbg_leaf ? a.dbg_leaf + (size_t)frame * a.nx * a.ny * T : nullptr;
     if (UNI) {
         // W walks per lane, advanced in lock step: their node fetches and box-sum reads are
@@ -742,7 +742,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
                 const double a2 = c2 ? __ddiv_rn((double)s2, (double)c2) : 0.0;
                 cur = (__dsub_rn(a1, a2) > thr) ? (int)n1.w : (int)n1.z;
             }
-            wleaf[(size_t)t * a.win_cap + slot] = ~cur;
+            store_leaf(wleaf, a.leaf_ls, t * a.win_cap + slot, ~cur);
             if (dleaf) dleaf[(size_t)agp[slot] * T + t] = ~cur;
         }
     }

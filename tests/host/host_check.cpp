@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <stdexcept>
 #include <string>
@@ -156,6 +157,7 @@ static void test_geometry() {
             q.f_rw = uniform ? 1 + (int)rnd(rmax) : 0; q.f_rh = uniform ? 1 + (int)rnd(rmax) : 0;
             q.lds_budget_kb = rnd(3) ? 0 : 20 + (int)rnd(140);
             if (rnd(8) == 0) { q.tile_x = 1 + (int)rnd(30); q.tile_y = 1 + (int)rnd(30); }
+
             Geom g;
             g.w = w; g.h = h; g.nx = nx; g.ny = ny; g.npatch = nx * ny; g.uniform = uniform;
             int rc = dh_choose_tile_(q, g);

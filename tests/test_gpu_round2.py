@@ -464,6 +464,14 @@ def test_first_regions_gathered_by_k_region(hp_mod, oracle, leaf_hist, min_hits)
         _check_frames(hp_mod, oracle, forest, model, frames[:3], synth.default_intrinsic(w, h),
                       rs.uniform(-100, 900, (3, 3)).astype(np.float32), rs.uniform(-1, 1, (3, 3)), np.array([3, 1, 2], dtype=np.uint8), full=False)
         _product_mode_check(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h))
+        # the pre-gathered regions are consumed and left zero by k_cluster (no per-batch fill): several batches of other frames
+        # through ONE predictor, every pose against the oracle's
+        K = synth.default_intrinsic(w, h)
+        other = synth.biwi_batch(5, w, h, first=140)
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            for batch in (frames, other, frames[:2], other[::-1].copy(), frames):
+                got = hp.predict_batch(batch, hp_mod.IntrinsicMatrix(K))
+                assert _poses_equal(got, oracle.predict_batch(forest, model, batch, K))
     finally:
         for k in env:
             os.environ.pop(k, None)
