@@ -256,12 +256,12 @@ def main():
         assert rp.tobytes() == hp.predict_batch(frames_np, intr).tobytes()
         rle_fps = host_rate(lambda: hp.predict_batch_rle(payloads, intr))
 
-    also = None
+    also = also_l2 = single_frame_us = None
     if world == 1 and not args.no_extras and not custom_workload():
         for q in hps:
             q.close()
         hp = None
-        also = other_configs(args, dev, stream)
+        also, also_l2, single_frame_us = other_configs(args, dev, stream)
 
     if rank == 0:
         total_frames = world * NF * args.steps
@@ -341,6 +341,8 @@ def main():
         }
         if also is not None:
             out["also"] = also
+            out["also_pose_l2_max"] = also_l2          # every leg's last poses vs the oracle on a sample of its frames: all 0.0
+            out["single_frame_us"] = single_frame_us
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], ref_poses = cpu_baseline(forest, model, frames_np, K, args.cpu_seconds)
             if last_was_b:
@@ -436,8 +438,10 @@ class Profiles:
         return next((v for k, v in self.sqd.items() if kernel in k), None)
 
 
-def rate(hp, frames_t, n, w, h, intr, stream, steps=5, warmup=2, graph=False):
-    """frames/s of `steps` device-resident batches (host wall clock around synchronised launches)."""
+def rate(hp, frames_t, n, w, h, intr, stream, steps=5, warmup=2, graph=False, latency=False):
+    """frames/s of `steps` device-resident batches (host wall clock around synchronised launches) and the pose records of the
+    last one.  latency=True: the host waits for every batch before it submits the next (one frame at a time, as the reference's
+    only caller does: examples/live_prediction.rs:76-86); returns microseconds per batch instead."""
     out = torch.zeros(n * 40, dtype=torch.uint8, device=frames_t.device)
     if graph:
         hp.graph_capture(frames_t.data_ptr(), n, w, h, intr, out.data_ptr())
@@ -449,67 +453,107 @@ def rate(hp, frames_t, n, w, h, intr, stream, steps=5, warmup=2, graph=False):
     t0 = time.perf_counter()
     for _ in range(steps):
         run()
+        if latency:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
-    return round(steps * n / (time.perf_counter() - t0), 1)
+    dt = time.perf_counter() - t0
+    from depthhead_amd._lib import POSE_DTYPE
+    poses = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE).copy()
+    return (round(dt / steps * 1e6, 1) if latency else round(steps * n / dt, 1)), poses
+
+
+def pose_l2(poses, ref) -> float:
+    """Largest L2 distance of mid_point (mm) / rotation (rad) between two pose arrays (0.0 = identical)."""
+    dm = np.linalg.norm(poses["mid_point"].astype(np.float64) - ref["mid_point"].astype(np.float64), axis=1)
+    dr = np.linalg.norm(poses["rotation"] - ref["rotation"], axis=1)
+    return float(max(dm.max(), dr.max()))
 
 
 def other_configs(args, dev, stream):
     """The other BASELINE configs and variants on this one GPU, a few untimed-for-`value` steps each, so that the
-    driver's line carries them (frames/s).  Same generators and seeds as the parity tests."""
+    driver's line carries them (frames/s).  Same generators and seeds as the parity tests.  Every leg's last poses are compared
+    with the oracle's on a small sample of its frames (`also_pose_l2_max`: must be 0.0)."""
     from depthhead_amd import synth
     from depthhead_amd.prediction import HoughPrediction, IntrinsicMatrix
-    res = {}
+    from oracle import pyoracle as po
+    res, l2 = {}, {}
     W, H = 640, 480
-    intr = IntrinsicMatrix(synth.default_intrinsic(W, H))
+    K = synth.default_intrinsic(W, H)
+    intr = IntrinsicMatrix(K)
     base = synth.biwi_batch(64, W, H)
     fr256 = torch.from_numpy(np.concatenate([base] * 4).view(np.int16)).to(dev)
     fitted = synth.fit_forest(10, 15, synth.FOREST_SEED_BASE + 2)
     rnd = synth.synth_forest(10, 15, synth.FOREST_SEED_BASE + 2)
+    cores = host_cores()
 
-    def one(forest, stride, frames_t, n, w, h, intr_, env=None, graph=False, steps=5):
+    def env_set(env):
         old = {k: os.environ.get(k) for k in (env or {})}
         os.environ.update(env or {})
+        return old
+
+    def env_restore(old):
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def one(name, forest, stride, frames_t, frames_np, n, w, h, K_, env=None, graph=False, steps=5, check=4, latency=False):
+        old = env_set(env)
         try:
             with HoughPrediction(forest, synth.ModelParams(stepwidth=stride), device=dev.index or 0) as hp:
                 hp.reserve(n, w, h)
-                return rate(hp, frames_t, n, w, h, intr_, stream, steps=steps, graph=graph)
+                v, poses = rate(hp, frames_t, n, w, h, IntrinsicMatrix(K_), stream, steps=steps, graph=graph, latency=latency)
         finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+            env_restore(old)
+        res[name] = v
+        if check:
+            k = min(check, n)
+            l2[name] = pose_l2(poses[:k], po.predict_batch(forest, synth.ModelParams(stepwidth=stride), frames_np[:k], K_, rect_mode=po.RECT_SAT, threads=cores))
 
-    res["synth_forest_10_15"] = one(rnd, 4, fr256, 256, W, H, intr)                 # BASELINE.md section 4's random stress forest
-    res["c1_stride10"] = one(fitted, 10, fr256, 256, W, H, intr)                    # configs[0] geometry (the trainer's step width)
-    res["general_path"] = one(fitted, 4, fr256, 256, W, H, intr, env={"DH_FORCE_GENERAL": "1"})   # mixed-rectangle traversal, forced
-    small = torch.from_numpy(synth.biwi_batch(64, 320, 240).view(np.int16)).to(dev)
-    intr_s = IntrinsicMatrix(synth.default_intrinsic(320, 240))
-    res["c5_320x240_s1_graph"] = one(fitted, 1, small, 64, 320, 240, intr_s, graph=True)   # configs[4] on one GPU, hipGraph replay
-    res["c5_320x240_s1_single_frame_graph"] = one(fitted, 1, small, 1, 320, 240, intr_s, graph=True, steps=50)
+    def in_flight(name, forest, stride, frames_t, n, w, h, depth=4, rounds=4):
+        """the way the headline is run: `depth` predictors on their own streams, batches in flight"""
+        hps, streams = [], [torch.cuda.Stream(dev) for _ in range(depth)]
+        try:
+            for _ in range(depth):
+                hps.append(HoughPrediction(forest, synth.ModelParams(stepwidth=stride), device=dev.index or 0))
+                hps[-1].reserve(n, w, h)
+            outs = [torch.zeros(n * 40, dtype=torch.uint8, device=dev) for _ in range(depth)]
+
+            def sweep(k):
+                for i in range(k):
+                    hps[i % depth].predict_batch_device(frames_t.data_ptr(), n, w, h, intr, outs[i % depth].data_ptr(), stream=streams[i % depth].cuda_stream)
+                torch.cuda.synchronize()
+            sweep(2 * depth)
+            t0 = time.perf_counter()
+            sweep(rounds * depth)
+            res[name] = round(rounds * depth * n / (time.perf_counter() - t0), 1)
+        finally:
+            for q in hps:
+                q.close()
+
+    base256 = np.concatenate([base] * 4)
+    one("synth_forest_10_15", rnd, 4, fr256, base256, 256, W, H, K)                 # BASELINE.md section 4's random stress forest
+    in_flight("synth_forest_10_15_4_in_flight", rnd, 4, fr256, 256, W, H)
+    one("c1_stride10", fitted, 10, fr256, base256, 256, W, H, K)                    # configs[0] geometry (the trainer's step width)
+    one("general_path", fitted, 4, fr256, base256, 256, W, H, K, env={"DH_FORCE_GENERAL": "1"})   # mixed-rectangle traversal, forced
+    small_np = synth.biwi_batch(64, 320, 240)
+    small = torch.from_numpy(small_np.view(np.int16)).to(dev)
+    Ks = synth.default_intrinsic(320, 240)
+    one("c5_320x240_s1_graph", fitted, 1, small, small_np, 64, 320, 240, Ks, graph=True)   # configs[4] on one GPU, hipGraph replay
+    one("c5_320x240_s1_single_frame_graph", fitted, 1, small, small_np, 1, 320, 240, Ks, graph=True, steps=50, check=1)
     c3 = synth.synth_forest(50, 20, synth.FOREST_SEED_BASE + 3)
-    res["c3_50x20_s2_32f"] = one(c3, 2, fr256, 32, W, H, intr, steps=3)              # configs[2]: 50 trees, depth 20, stride 2, batch 32
-    # the same config the way the headline is run: four predictors on four streams, batches in flight
-    hps, streams = [], [torch.cuda.Stream(dev) for _ in range(4)]
-    try:
-        for _ in range(4):
-            hps.append(HoughPrediction(c3, synth.ModelParams(stepwidth=2), device=dev.index or 0))
-            hps[-1].reserve(32, W, H)
-        outs = [torch.zeros(32 * 40, dtype=torch.uint8, device=dev) for _ in range(4)]
-
-        def sweep(k):
-            for i in range(k):
-                hps[i % 4].predict_batch_device(fr256.data_ptr(), 32, W, H, intr, outs[i % 4].data_ptr(), stream=streams[i % 4].cuda_stream)
-            torch.cuda.synchronize()
-        sweep(8)
-        t0 = time.perf_counter()
-        sweep(16)
-        res["c3_50x20_s2_32f_4_in_flight"] = round(16 * 32 / (time.perf_counter() - t0), 1)
-    finally:
-        for q in hps:
-            q.close()
+    one("c3_50x20_s2_32f", c3, 2, fr256, base256, 32, W, H, K, steps=3, check=2)    # configs[2]: 50 trees, depth 20, stride 2, batch 32
+    in_flight("c3_50x20_s2_32f_4_in_flight", c3, 2, fr256, 32, W, H)
     res["unit"] = "frames/s"
-    return res
+    # latency of ONE frame, the host waiting for each pose before the next frame (live_prediction.rs:76-86): microseconds per frame
+    lat = {}
+    res_keep = dict(res)
+    one("lat_320", fitted, 1, small, small_np, 1, 320, 240, Ks, graph=True, steps=200, check=0, latency=True)
+    one("lat_640", fitted, 4, fr256, base256, 1, W, H, K, graph=True, steps=200, check=0, latency=True)
+    lat = {"320x240_stride1": res.pop("lat_320"), "640x480_stride4": res.pop("lat_640"), "unit": "us per frame, hipGraph replay, host sync after every frame"}
+    assert set(res) == set(res_keep)
+    return res, l2, lat
 
 
 def host_cores() -> int:

@@ -66,7 +66,7 @@ def build(force: bool = False, verbose: bool = False, knobs: bool = False) -> st
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

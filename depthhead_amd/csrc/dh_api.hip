@@ -25,6 +25,35 @@
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? DH_ENOMEM : DH_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// ------------------------------------------------------------------ roctx ranges (tracing)
+// With profiling on (dh_set_profiling) every kernel launch of a batch sits inside a named roctx range on the host thread --
+// "dh:boxsum", "dh:traverse", "dh:emit", "dh:vote", "dh:cluster", and "dh:batch n=..." around them -- which rocprofv3
+// --marker-trace shows beside the kernel trace.  The marker library is looked up at run time (librocprofiler-sdk-roctx.so,
+// else libroctx64.so): the product library has no link-time dependency on a profiler, and without one the ranges are no-ops.
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(name, RTLD_LAZY | RTLD_GLOBAL)) {
+                push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() { static const Roctx r; return r; }      // (thread-safe initialisation; only ever touched with profiling on)
+struct Range {
+    bool on;
+    Range(bool enabled, const char *name) : on(enabled && roctx().push) { if (on) roctx().push(name); }
+    ~Range() { if (on) roctx().pop(); }
+};
+}   // namespace
+
 extern "C" const char *dh_last_error(void) { return dh_err_get_(); }
 extern "C" int dh_version(void) { return DH_VERSION; }
 
@@ -511,6 +540,9 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     uint32_t *rot_grid = p->counters + p->cap_frames + (size_t)p->cap_frames * DH_POSGRID + (size_t)f0 * DH_GRID3;
     const size_t hoff = (size_t)f0 * p->hits_cap;
     const uint16_t *fr = frames + (size_t)f0 * w * h;
+    char batch_name[48];
+    snprintf(batch_name, sizeof batch_name, "dh:batch n=%d %dx%d", n, w, h);
+    Range batch_range(profile, batch_name);
     if (profile) HIP_TRY(hipEventRecord(p->ev[0], s));
     uint32_t *box = g.uniform ? p->box + (size_t)f0 * g.box_rows * ((size_t)g.box_plane << g.swz_log2) : nullptr;
     // tile flags: one byte per tile, frames packed back to back (the slice always starts at the frame the memset covered)
@@ -537,7 +569,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ba.mask_blocks = (g.box_rows + 31) / 32;
         ba.blk_mask = p->box_mask ? p->box_mask + (size_t)f0 * ba.mask_blocks * g.box_parts : nullptr;
         ba.blocks_per_frame = (ba.parts * ba.bands + 3) / 4;
-        HIP_TRY(dh_launch_boxsum(ba, s));
+        { Range r(profile, "dh:boxsum"); HIP_TRY(dh_launch_boxsum(ba, s)); }
     }
     if (g.npatch > 0 && !g.uniform) {
         PixFlagArgs fa{};
@@ -546,7 +578,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         fa.tpx = g.px * (int)p->params.stepwidth; fa.tpy = g.py * (int)p->params.stepwidth;
         fa.tfw = (g.px - 1) * (int)p->params.stepwidth + (int)p->params.subimage_width;
         fa.tfh = (g.py - 1) * (int)p->params.stepwidth + (int)p->params.subimage_height;
-        HIP_TRY(dh_launch_pixflags(fa, s));
+        { Range r(profile, "dh:pixflags"); HIP_TRY(dh_launch_pixflags(fa, s)); }
     }
     // product mode: the flagged tiles as compact lists, so that the workgroups of empty tiles sit at the end of k_traverse's grid
     // (with the taps on, every tile position keeps its workgroup: those of empty tiles write the taps' "background")
@@ -555,7 +587,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     const bool use_list = p->tile_list && g.npatch > 0 && !leaf_out && !flags_out && !p->debug;
     uint32_t *tl_list = use_list ? p->tile_list + (size_t)chunk * 8 * (p->tile_list_stride + 1) : nullptr;
     uint32_t *tl_count = use_list ? tl_list + 8 * p->tile_list_stride : nullptr;
-    if (use_list) HIP_TRY(dh_launch_tile_list(tile_flags, n, g.tiles_x * g.tiles_y, tl_list, tl_count, (uint32_t)p->tile_list_stride, s));
+    if (use_list) { Range r(profile, "dh:tile_list"); HIP_TRY(dh_launch_tile_list(tile_flags, n, g.tiles_x * g.tiles_y, tl_list, tl_count, (uint32_t)p->tile_list_stride, s)); }
     if (profile) HIP_TRY(hipEventRecord(p->ev[4], s));
     if (g.npatch > 0) {
         TraverseArgs ta{};
@@ -589,7 +621,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.dbg_leaf = leaf_out ? leaf_out : p->debug ? p->dbg_leaf + (size_t)f0 * g.npatch * p->n_trees : nullptr;
         ta.dbg_flags = flags_out ? flags_out : p->debug ? p->dbg_flags + (size_t)f0 * g.npatch : nullptr;
         if (use_list) { ta.tile_list = tl_list; ta.tile_list_count = tl_count; ta.tile_list_stride = (uint32_t)p->tile_list_stride; }
-        HIP_TRY(dh_launch_traverse(ta, g.lds, s));
+        { Range r(profile, "dh:traverse"); HIP_TRY(dh_launch_traverse(ta, g.lds, s)); }
         if (profile) HIP_TRY(hipEventRecord(p->ev[5], s));
         if (!traverse_only) {
             EmitArgs ea{};
@@ -606,7 +638,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
 #ifdef DH_PROFILING_KNOBS
             ea.stop = p->knobs.emit_stop;
 #endif
-            HIP_TRY(dh_launch_emit(ea, s));
+            { Range r(profile, "dh:emit"); HIP_TRY(dh_launch_emit(ea, s)); }
         }
     } else if (profile) HIP_TRY(hipEventRecord(p->ev[5], s));
     if (profile) HIP_TRY(hipEventRecord(p->ev[1], s));
@@ -622,7 +654,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
 #ifdef DH_PROFILING_KNOBS
         va.stop = p->knobs.vote_stop;
 #endif
-        HIP_TRY(dh_launch_vote(va, s));
+        { Range r(profile, "dh:vote"); HIP_TRY(dh_launch_vote(va, s)); }
     }
     if (profile) HIP_TRY(hipEventRecord(p->ev[2], s));
     {
@@ -648,9 +680,9 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
             ca.pre_region = p->pre_region + (size_t)f0 * 2 * DH_REGION_CELLS;
             ca.pre_slices = slices;
             ca.pre_min_hits = p->pre_min_hits;
-            HIP_TRY(dh_launch_region(ca, s));
+            { Range r(profile, "dh:region"); HIP_TRY(dh_launch_region(ca, s)); }
         }
-        HIP_TRY(dh_launch_cluster(ca, s));
+        { Range r(profile, "dh:cluster"); HIP_TRY(dh_launch_cluster(ca, s)); }
     }
     if (profile) { HIP_TRY(hipEventRecord(p->ev[3], s)); p->ev_valid = true; }
     return DH_OK;

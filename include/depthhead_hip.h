@@ -228,7 +228,9 @@ int dh_biwi_parse_cal(const char *text, size_t len, float K[9]);
 int dh_biwi_parse_pose(const uint8_t *buf, size_t len, const float K[9], float pos3d[3], float pos2d[2], float rot[3]);
 
 /* ---- profiling ---- */
-int dh_set_profiling(dh_predictor *p, int on); /* HIP events around each kernel, on the launch stream */
+int dh_set_profiling(dh_predictor *p, int on); /* HIP events around each kernel, on the launch stream; and roctx ranges
+                                                * ("dh:batch ...", "dh:boxsum", "dh:traverse", "dh:emit", "dh:vote", "dh:cluster") around the
+                                                * launches, visible to rocprofv3 --marker-trace when a roctx library is present */
 int dh_get_timing(dh_predictor *p, dh_timing *out); /* synchronises the recorded events */
 
 /* ---- parity taps (tests only; each refers to the LAST batch run on this predictor) ----
