@@ -194,7 +194,6 @@ struct VoteArgs {
     int stop;               // profiling knob (env DH_VOTE_STOP): 1 / 2 / 3 = return after the LDS set-up / the hit records / the leaf histogram
     int cell_fast;          // w and h are multiples of 20: a vote's guess-grid cell may be taken from an approximate quotient (vote_positions)
     float sx, sy;           // 20 / w, 20 / h
-    float ax, bx, ay, by;   // pinhole matrix: fx 20 / w, cx 20 / w, fy 20 / h, cy 20 / h (the approximate cell test of vote_positions)
 };
 
 struct ClusterArgs {
