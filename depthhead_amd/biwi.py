@@ -2,7 +2,7 @@
 
 Mirrors `/root/reference/src/db_reader/biwi.rs`: `read_depth` (:81-103), `read_cal` (:27-60),
 `read_gt` (:63-77) and the directory walk of `BiwiReader::person` (:263-314).  The three format
-decoders run in libdepthhead_hip.so (csrc/dh_biwi.hip); this module marshals bytes and walks
+decoders run in libdepthhead_hip.so (csrc/dh_biwi.cpp); this module marshals bytes and walks
 directories.  `encode_depth` is the inverse of `read_depth`, used to write fixtures and to
 round-trip test the decoder (the database itself cannot be downloaded here).
 """

@@ -54,6 +54,8 @@ def build(force: bool = False, verbose: bool = False, knobs: bool = False) -> st
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
     cc, defs = hipcc(), (["-DDH_PROFILING_KNOBS"] if knobs else [])
+    if os.environ.get("DH_BUILD_DEFS"):            # experiments only, e.g. DH_BUILD_DEFS="-DTRAV_THREADS=512"
+        defs += os.environ["DH_BUILD_DEFS"].split()
 
     def compile_one(src: str) -> str:
         path, obj = os.path.join(CSRC, src), os.path.join(odir, src + ".o")

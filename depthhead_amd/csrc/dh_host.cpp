@@ -286,7 +286,11 @@ int dh_choose_tile_(const TileQuery &p, Geom &g) {
         while (g.top_levels > 0 && (size_t)p.n_trees * (1u << g.top_levels) * 12 > 48 * 1024) --g.top_levels;
     }
     const int top_words = g.uniform && p.absorb_ok ? (int)p.n_trees * (1 << g.top_levels) * 3 : 0;
+#ifdef TRAV_THREADS
+    const long max_win = TRAV_THREADS;
+#else
     const long max_win = 1024;      // one thread per window position in the gate
+#endif
     long best = -1;
     for (int py = 1; py <= std::min(g.ny, 64); ++py)
         for (int px = 1; px <= std::min(g.nx, 64); ++px) {

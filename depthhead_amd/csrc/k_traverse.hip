@@ -17,7 +17,10 @@
 // rectangle inside a patch sums to < sw*sh*65535 < 2^32, checked at predictor creation, so the
 // differences are exact) and one rectangle mean costs 4 LDS reads instead of the reference's O(area)
 // pixel loop (types.rs:317-339).
+#ifndef TRAV_THREADS
 #define TRAV_THREADS 1024
+#endif
+#define TRAV_WMAX (4096 / TRAV_THREADS)     // lock-step walks per lane of the walk-table path: 4 at 1024 threads (64 VGPRs), 8 at 512 (128)
 #define TRAV_WAVES (TRAV_THREADS / WAVE)
 #define ROWS_IN_FLIGHT 8
 
@@ -513,7 +516,7 @@ __device__ __forceinline__ void walk_general_int(const TraverseArgs &a, const ui
 #endif
 
 template <bool UNI, bool GI>
-__global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
+__global__ void __launch_bounds__(TRAV_THREADS, TRAV_THREADS / 128) k_traverse(TraverseArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int T = (int)a.f.n_trees;
@@ -706,12 +709,20 @@ __global__ void __launch_bounds__(TRAV_THREADS, 8) k_traverse(TraverseArgs a) {
         // fewer -- every lock-step level of a chain is a node gather of the whole wave, whatever its lanes hold)
         const int wave_first = __builtin_amdgcn_readfirstlane(tid & ~(WAVE - 1));
         const int all_passes = (total - wave_first + TRAV_THREADS - 1) / TRAV_THREADS;
-        const int per_lane = all_passes > 4 ? (total + TRAV_THREADS - 1) / TRAV_THREADS : all_passes;
+        const int per_lane = all_passes > TRAV_WMAX ? (total + TRAV_THREADS - 1) / TRAV_THREADS : all_passes;
         if (GI) {                   // (uniform path: the second template flag selects the absorbing-leaf walk table)
             if (per_lane <= 1) walk_absorb<1>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
             else if (per_lane == 2) walk_absorb<2>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
             else if (per_lane == 3) walk_absorb<3>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+#if TRAV_WMAX >= 8
+            else if (per_lane == 4) walk_absorb<4>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+            else if (per_lane == 5) walk_absorb<5>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+            else if (per_lane == 6) walk_absorb<6>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+            else if (per_lane == 7) walk_absorb<7>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+            else walk_absorb<8>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+#else
             else walk_absorb<4>(a, sat, top, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
+#endif
         } else
         if (per_lane <= 1) walk_uniform<1>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);
         else if (per_lane == 2) walk_uniform<2>(a, sat, wleaf, dleaf, active, agp, n_active, total, cx, ss, T);

@@ -52,7 +52,7 @@ def _edge_tile_is_cut(geo, model, w):
     """True when the tiling has a last tile column that is cut by the right frame edge such that it owns fewer
     16-byte groups per plane than a full tile: the case the direct-to-LDS region copy got wrong before fc33f8a
     (it copied all q/4 groups of every plane and so read past the 4 words of slack behind the image's last
-    column, dh_kernels.hip `q4_tile`)."""
+    column, k_traverse.hip `q4_tile`)."""
     step, sw = model.stepwidth, model.subimage_width
     lw = sw // 2
     nx = (w - (sw - lw) - lw + step - 1) // step
