@@ -4,6 +4,10 @@ per-frame `predict_parameter` call replaced by frame BATCHES through the GPU pre
 reference's report page computes from `evaluation.json` (`examples/eval_files/overview.html`: `compDistance` :175-186,
 `compAccuracy` :82-90, `meansqareerror` :236-251, thresholds 0, 5, ..., 95 :254-257).
 
+The reference evaluates with the serial `predict_parameter` (db_evaluate.rs:296); batches here go through the
+`predict_parameter_parallel`-equivalent GPU path, which is numerically identical by construction (prediction.rs:386 vs :407:
+only the forest call differs, and the parity tests hold both to the same oracle).
+
 The JSON this writes has the reference's shape -- `{"persons": [...], "trained_tree_path": "...", "res": [[person,
 {"guess_midpoint": [[f32; 3]...], "guess_rot": ..., "truth_midpoint": ..., "truth_rot": ...}], ...]}` (serde writes the
 `(usize, EvalEntrie)` tuples as 2-element arrays) -- so the reference's own `overview.html` renders it.

@@ -104,3 +104,22 @@ def test_evaluate_synthetic_biwi_tree(tmp_path, hip_lib, oracle):
         assert res2d.res[0][1].guess_midpoint[j] == [float(v) for v in mid] and res2d.res[0][1].guess_rot[j] == [0.0, 0.0, 0.0]
     s = res.summary()
     assert s["frames"] == 8 and s["midp_mse"] >= 0
+
+
+def test_evaluation_json_maps_non_finite_values_to_null():
+    """serde_json writes `null` for a non-finite f32 / f64; a bare NaN / Infinity (Python's default) would make the reference's
+    report page reject the whole file."""
+    import json
+    from depthhead_amd.evaluate import EvalEntry, EvaluationResult
+    e = EvalEntry()
+    e.guess_midpoint = [[1.0, float("nan"), 3.0], [float("inf"), -2.0, float("-inf")]]
+    e.guess_rot = [[0.0, 1.5, -1.5], [0.0, 0.0, 0.0]]
+    e.truth_midpoint = [[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]]
+    e.truth_rot = [[0.0, 1.0, -1.0], [0.0, 0.0, 0.0]]
+    r = EvaluationResult(persons=[7], trained_tree_path="forest.json", res=[(7, e)])
+    text = r.to_json()
+    assert "NaN" not in text and "Infinity" not in text
+    doc = json.loads(text)
+    assert doc["persons"] == [7] and doc["res"][0][0] == 7
+    assert doc["res"][0][1]["guess_midpoint"] == [[1.0, None, 3.0], [None, -2.0, None]]
+    assert doc["res"][0][1]["truth_rot"] == [[0.0, 1.0, -1.0], [0.0, 0.0, 0.0]]

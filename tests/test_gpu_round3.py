@@ -271,3 +271,30 @@ def test_bad_payload_batches_come_back_as_error_codes(hp_mod, hip_lib):
         # the predictor is still usable
         out = hp.predict_batch_rle([good], hp_mod.IntrinsicMatrix(synth.default_intrinsic(96, 96)))
         assert out.shape == (1,)
+
+
+# ------------------------------------------------------------------ profiling: HIP events + roctx ranges
+def test_profiling_changes_nothing_and_times_every_kernel(hp_mod, oracle):
+    """dh_set_profiling: HIP events around every kernel and roctx ranges around every launch (the marker library is looked up at
+    run time; absent, the ranges are no-ops).  Same poses with it on, every kernel's duration positive and inside the total;
+    dh_get_timing before any profiled batch is DH_ESTATE."""
+    from depthhead_amd._lib import DepthheadError
+    forest = synth.fit_forest(6, 10, synth.FOREST_SEED_BASE + 9, n_frames=12, subset=1500)
+    model = synth.ModelParams(stepwidth=4)
+    frames = synth.biwi_batch(6, 320, 240, first=40)
+    K = synth.default_intrinsic(320, 240)
+    ref = oracle.predict_batch(forest, model, frames, K)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        with pytest.raises(DepthheadError) as ei:
+            hp.timing()
+        assert ei.value.code == -6
+        a = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        hp.set_profiling(True)
+        b = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+        t = hp.timing()
+        hp.set_profiling(False)
+        c = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K))
+    assert _poses_equal(a, ref) and _poses_equal(b, ref) and _poses_equal(c, ref)
+    parts = [t[k] for k in ("boxsum_ms", "traverse_ms", "emit_ms", "vote_ms", "cluster_ms")]
+    assert all(p > 0.0 for p in parts) and t["n_frames"] == 6
+    assert abs(sum(parts) - t["total_ms"]) < 0.02 * t["total_ms"] + 1e-3
