@@ -229,3 +229,22 @@ def test_cpp_example_compiles_and_links(tmp_path):
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     assert os.path.exists(exe)
+
+
+def test_every_entry_point_runs_inside_the_exception_guard():
+    """include/depthhead_hip.h: "never throws or aborts across the boundary".  Every `extern "C" int dh_*` definition of the
+    library is either generated by the DH_API macro (dh_api.hip: body inside dh_guard_) or calls dh_guard_ itself (dh_biwi.cpp);
+    the only unguarded definitions are the two that cannot throw (dh_version, dh_last_error)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "depthhead_amd", "csrc")
+    api = open(os.path.join(csrc, "dh_api.hip")).read()
+    guarded = set("dh_" + m for m in re.findall(r"^DH_API\((\w+),", api, flags=re.M))
+    assert "dh_guard_(" in api[api.index("#define DH_API"):api.index("#define DH_API") + 300]
+    raw = set(re.findall(r'extern "C" (?:int|const char \*)\s*(dh_\w+)\(', api))
+    assert raw <= {"dh_version", "dh_last_error"}, raw
+    biwi = open(os.path.join(csrc, "dh_biwi.cpp")).read()
+    for name, body in re.findall(r'extern "C" int (dh_\w+)\([^)]*\) \{(.*?)\n\}', biwi, flags=re.S):
+        assert "dh_guard_(" in body, name
+        guarded.add(name)
+    declared = set(declared_functions()) - {"dh_version", "dh_last_error"}
+    assert declared == guarded, (sorted(declared - guarded), sorted(guarded - declared))
