@@ -50,16 +50,28 @@ def test_pyref_with_guess_overrides(oracle):
 
 
 def test_pyref_helpers_against_the_reference_kats():
-    """The reference's own known answers for the helpers (src/types.rs:476-488, src/meancov_estimation.rs:450-533), through
-    this restatement as well."""
+    """The reference's OWN known answers for the helpers -- test_intrinsic (src/types.rs:476-488), test_mean_cov3 / test_det_2_3_trace /
+    test_inverse / test_mat_vec_mul (src/meancov_estimation.rs:461-525), same numbers and tolerances -- through this restatement
+    as well (tests/test_oracle_kat.py holds the C oracle to them)."""
     F32, F64 = np.float32, np.float64
-    intr = pyref.Intrinsic([[560.0, 0.0, 320.0], [0.0, 560.0, 240.0], [0.0, 0.0, 1.0]])
-    p = intr.img_to_space([F32(100.0), F32(50.0)], F32(800.0))
-    back = intr.space_to_img(p)
-    assert abs(float(back[0]) - 100.0) < 1e-3 and abs(float(back[1]) - 50.0) < 1e-3 and float(p[2]) == 800.0
-    m = [[1.0, 2.0, 3.0], [0.0, 1.0, 4.0], [5.0, 6.0, 0.0]]
-    assert float(pyref.mat3_det(m, F64)) == 1.0
-    inv = pyref.mat3_inv(m, F64)
-    assert [[float(x) for x in r] for r in inv] == [[-24.0, 18.0, 5.0], [20.0, -15.0, -4.0], [-5.0, 4.0, 1.0]]
-    assert float(pyref.trace_of_cov(np.array([[10.0, 20.0, 30.0], [12.0, 22.0, 32.0]]), F64)) == 6.0
-    assert np.isnan(pyref.trace_of_cov(np.array([[1.0, 2.0, 3.0]]), F64))            # n = 1: 0 / 0
+    # types.rs:476-488
+    intr = pyref.Intrinsic([[22.0, 11.4, 12.11], [2.1, 4.1, 2.11], [1.3, 3.1, 19.0]])
+    p2 = intr.space_to_img([F32(11.0), F32(12.0), F32(32.2)])
+    assert abs(float(p2[0]) - 1.15896578) < 1e-4 and abs(float(p2[1]) - 0.21143073) < 1e-4
+    back = intr.img_to_space(p2, F32(32.2))
+    assert all(abs(float(b) - e) < 1e-4 for b, e in zip(back, (11.0, 12.0, 32.2)))
+    # meancov_estimation.rs:461-490 (the trace is what the path uses: sum of the three diagonal answers)
+    v = np.array([[1.0, 2.0, 3.0], [1.2, 1.0, 3.2], [-1.0, -2.1, 3.0], [0.0, 1.0, 0.0]])
+    assert abs(float(pyref.trace_of_cov(v, F64)) - (1.0266666 + 3.1691666 + 2.36)) < 3e-3
+    v = np.array([[-32.48225021362305, 24.72743034362793, -3.9425208568573], [-25.82341957092285, -25.307233810424805, 1.955498456954956],
+                  [35.37421417236328, -18.529083251953125, -5.888242721557617], [43.30265808105469, -60.69481658935547, -15.176074028015137],
+                  [32.97354507446289, -7.171285629272461, -3.897606134414673]])
+    assert abs(float(pyref.trace_of_cov(v, F64)) - (1341.63076476 + 954.396794746 + 38.573568346)) < 3e-3
+    assert np.isnan(pyref.trace_of_cov(np.array([[1.0, 2.0, 3.0]]), F64))            # n = 1: 0 / 0 (a one-vote leaf never votes)
+    # :492-500, :502-515, :517-525
+    assert abs(float(pyref.mat3_det([[1.0, 3.0, 22.0], [2.0, 44.0, 1.0], [2.0, 0.0, 3.1]], F64)) - -1812.199) < 1e-3
+    inv = pyref.mat3_inv([[2.3, 1.4, 12.11], [2.1, 44.11, 2.11], [1.3, 4.1, 19.0]], F64)
+    want = [[0.65540671, 0.01821446, -0.4197583], [-0.02936075, 0.02209108, 0.01626034], [-0.03850788, -0.00601328, 0.07784307]]
+    assert all(abs(float(inv[i][j]) - want[i][j]) < 1e-3 for i in range(3) for j in range(3))
+    mv = pyref.mat_vec([[1.3, 12.1, 2.3], [3.1, 33.1, 14.1], [1.0, 2.0, 3.0]], [11.0, 12.0, 32.2], F64)
+    assert all(abs(float(a) - b) < 1e-3 for a, b in zip(mv, (233.56, 885.32, 131.6)))
