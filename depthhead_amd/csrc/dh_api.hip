@@ -150,7 +150,7 @@ struct dh_predictor {
     uint32_t *leaf_hits = nullptr;   // [cap][n_leaves] rotation-vote histogram (inside `counters`), only for forests of <= DH_LEAF_HIST_MAX leaves
     size_t zero_words = 0;           // words of `counters` zeroed before every batch
     uint32_t hits_cap = 0;
-    uint32_t *pre_region = nullptr;  // [pre_cap][2][26^3] first regions of both accumulators, gathered by k_region (small batches with many hit records)
+    uint32_t *pre_region = nullptr;  // [pre_cap][2][64^3] the cells of both accumulators around the initial guesses, gathered by k_region (small batches with many hit records)
     int pre_cap = 0;
     uint32_t pre_min_hits = 0;       // frames with fewer hit records are gathered by k_cluster alone
     uint32_t *counters = nullptr;    // [n] hit_count | [n][400] pos_grid | [n][8000] rot_grid (one memset)
@@ -466,9 +466,7 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     if (!p->knobs.no_region && hits_cap >= (leaf_hist ? 8 : 4) * (size_t)p->pre_min_hits) {
         // k_region serves batches of up to 128 frames (beyond that the (frame, accumulator) workgroups of k_cluster fill the chip themselves)
         p->pre_cap = std::min(cap, 128);
-        STEP(dev_alloc(p, &p->pre_region, (size_t)p->pre_cap * 2 * DH_REGION_CELLS));
-        // zeroed once: k_cluster leaves every pre-gathered region it consumes zero again, so there is no per-batch fill
-        if (rc == DH_OK && hipMemsetAsync(p->pre_region, 0, (size_t)p->pre_cap * 2 * DH_REGION_CELLS * sizeof(uint32_t), p->own_stream) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(pre_region)");
+        STEP(dev_alloc(p, &p->pre_region, (size_t)p->pre_cap * 2 * DH_SUPER_CELLS));   // (2 MB per frame; zeroed per batch, before k_region)
     }
     STEP(dev_alloc(p, &p->win_patch, (size_t)cap * std::max(g.win_cap, 1)));
     p->leaf_ls = p->n_leaves <= 65535u ? 1 : 2;
@@ -677,9 +675,13 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         // few frames with many hit records each: the first region of every accumulator is gathered by several workgroups
         const int slices = std::min(16, 256 / std::max(n, 1));
         if (p->pre_region && slices >= 2 && f0 + n <= p->pre_cap && ca.iterations > 0) {
-            ca.pre_region = p->pre_region + (size_t)f0 * 2 * DH_REGION_CELLS;
+            ca.pre_region = p->pre_region + (size_t)f0 * 2 * DH_SUPER_CELLS;
             ca.pre_slices = slices;
             ca.pre_min_hits = p->pre_min_hits;
+            // (a kernel node inside a captured graph, like the counters' fill)
+            const size_t pre_bytes = (size_t)n * 2 * DH_SUPER_CELLS * sizeof(uint32_t);
+            if (p->capturing) HIP_TRY(dh_launch_zero(ca.pre_region, pre_bytes, s));
+            else HIP_TRY(hipMemsetAsync(ca.pre_region, 0, pre_bytes, s));
             { Range r(profile, "dh:region"); HIP_TRY(dh_launch_region(ca, s)); }
         }
         { Range r(profile, "dh:cluster"); HIP_TRY(dh_launch_cluster(ca, s)); }

@@ -10,7 +10,8 @@
 #define DH_GRID3 8000          // 20^3
 #define DH_POSGRID 400         // 20^2
 #define DH_ROTPARTS 120
-#define DH_REGION_CELLS (26 * 26 * 26)   // k_cluster's LDS region of an accumulator (RG^3 in dh_kernels.hip)
+#define DH_REGION_CELLS (26 * 26 * 26)   // k_cluster's LDS region of an accumulator (RG^3 in k_cluster.hip)
+#define DH_SUPER_CELLS (64 * 64 * 64)    // k_region's block of an accumulator in global memory (SRG^3 in k_cluster.hip)
 
 // leaf_flags bits (written by k_leaf_prepare)
 #define LF_PROB 1u   // prob > 0.0                      (prediction.rs:590)
@@ -215,7 +216,7 @@ struct ClusterArgs {
     const double  *rot_guess;  // nullable, n*3
     const uint8_t *guess_mask; // nullable, n
     dh_pose  *out;
-    uint32_t *pre_region;      // nullable [n][2][26^3]: regions around the initial guesses, gathered by k_region (zeroed per batch)
+    uint32_t *pre_region;      // nullable [n][2][64^3]: the accumulators' cells around the initial guesses, gathered by k_region (zeroed per batch)
     int       pre_slices;      // workgroups per (frame, accumulator) of k_region
     uint32_t  pre_min_hits;    // frames with fewer hit records are left to k_cluster alone (both kernels read the same count)
     int32_t  *dbg_guess;       // nullable [n][6]
@@ -266,6 +267,7 @@ struct Mat3Arg { float m[9]; };
 hipError_t dh_launch_blur_u16(const uint16_t *in, uint16_t *tmp, uint16_t *out, int n, int w, int h, const float *kern, int klen, hipStream_t s);
 hipError_t dh_launch_argmax2d(const uint16_t *hough, const uint16_t *frames, int n, int w, int h, const float kinv[9], dh_pose *out, hipStream_t s);
 hipError_t dh_launch_rle_decode(const RleArgs &a, hipStream_t s);
+hipError_t dh_region_init();             // k_region's dynamic-LDS attribute (called by dh_kernels_init, device current)
 hipError_t dh_launch_zero(void *ptr, size_t bytes, hipStream_t s);   // ptr, bytes multiples of 16
 hipError_t dh_launch_mask(const AuxArgs &a, hipStream_t s);
 hipError_t dh_launch_hough2d(const AuxArgs &a, uint16_t *out, hipStream_t s);

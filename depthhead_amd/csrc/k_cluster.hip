@@ -25,6 +25,17 @@
 #define RG 26                   // region edge; the window may sit at offsets 0..RG-20 inside it
 #define RG3 (RG * RG * RG)
 static_assert(RG3 == DH_REGION_CELLS, "dh_internal.h: DH_REGION_CELLS");
+// k_region's block of an accumulator in global memory (small batches with many hit records per frame): SRG^3 cells
+// around the initial guess, from which k_cluster cuts its regions -- the window may travel SPAD cells either way
+// on every axis before a region has to be gathered from the hit records again
+#define SRG 64
+#define SRG3 (SRG * SRG * SRG)
+#define SPAD ((SRG - RG) / 2)
+static_assert(SRG3 == DH_SUPER_CELLS, "dh_internal.h: DH_SUPER_CELLS");
+// ... and of the rotation accumulator (first RRG^3 words of its slot): gathered in LDS, one workgroup per CU
+#define RRG 32
+#define RRG3 (RRG * RRG * RRG)
+#define RPAD ((RRG - RG) / 2)
 
 // exists c in [lo,hi] and d in [0,len) with c == start + d (i32 wrapping, like the reference's
 // release-mode `pos + offset`)?
@@ -35,6 +46,7 @@ __device__ __forceinline__ bool range_hits_span(int32_t lo, int32_t hi, int32_t 
 
 // Position votes of hit record i that fall into the region: lane `sub` of `nsub` takes the leaf's offset votes
 // sub, sub + nsub, ... (prediction.rs:647-667).
+template <int EDGE>
 __device__ __forceinline__ void cluster_add_votes(const ClusterArgs &a, uint32_t *region, const HitRec *hits, const HitBox *box,
                                                   uint32_t i, uint32_t sub, uint32_t nsub, const int32_t org[3]) {
     const float4 rec = *(const float4 *)(hits + i);
@@ -48,13 +60,12 @@ __device__ __forceinline__ void cluster_add_votes(const ClusterArgs &a, uint32_t
         uint32_t dx = (uint32_t)f32_as_i32(nx) - (uint32_t)org[0];                                     // :667
         uint32_t dy = (uint32_t)f32_as_i32(ny) - (uint32_t)org[1];
         uint32_t dz = (uint32_t)f32_as_i32(__fdiv_rn(nz, (float)DH_ZSCALEFACTOR)) - (uint32_t)org[2];
-        if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], v);
+        if (dx < EDGE && dy < EDGE && dz < EDGE) atomicAdd(&region[(dx * EDGE + dy) * EDGE + dz], v);
     }
 }
 
 // Shared-memory carve-up of k_cluster / k_region.
 struct ClShared {
-    uint32_t *region;              // [RG3]
     float *prod;                   // [CL_PROD_CAP * 4], doubles as the survivor list of the gathers
     unsigned long long *red64;     // [CL_WAVES]
     uint32_t *red32;               // [CL_WAVES]
@@ -128,13 +139,15 @@ __device__ __forceinline__ void cl_initial_guess(const ClusterArgs &a, const int
     }
 }
 
-// Adds to the (zeroed) LDS region with origin `org` every vote of accumulator `which` that falls into it, from the hit
+// Adds to the (zeroed) block `region` of EDGE^3 cells with origin `org` -- k_cluster's LDS region, or k_region's block of the
+// accumulator in global memory -- every vote of accumulator `which` that falls into it, from the hit
 // records [h0, h1) of the frame -- or, for rotation votes of forests with a leaf histogram, from the leaves [l0, l1).
-// Integer atomics: exact and order-free, so any split of the ranges over workgroups sums to the same region.
+// Integer atomics: exact and order-free, so any split of the ranges over workgroups sums to the same block.
+template <int EDGE>
 __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which, const int frame, const int32_t org[3],
-                                          const uint32_t h0, const uint32_t h1, const uint32_t l0, const uint32_t l1, const ClShared sh) {
+                                          const uint32_t h0, const uint32_t h1, const uint32_t l0, const uint32_t l1, const ClShared sh,
+                                          uint32_t *region) {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    uint32_t *region = sh.region;
     float *prod = sh.prod;
     uint32_t &s_total = *sh.s_total;
     const HitRec *hits = a.hits + (size_t)frame * a.hits_cap;
@@ -158,8 +171,8 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const uint32_t i = i0 + j * CL_THREADS + tid, fc = (uint32_t)b1[j].w;
-                const bool keep = i < h1 && (fc & LF_OFF) && range_hits_span(b0[j].x, b0[j].w, org[0], RG) &&
-                                  range_hits_span(b0[j].y, b1[j].x, org[1], RG) && range_hits_span(b0[j].z, b1[j].y, org[2], RG);
+                const bool keep = i < h1 && (fc & LF_OFF) && range_hits_span(b0[j].x, b0[j].w, org[0], EDGE) &&
+                                  range_hits_span(b0[j].y, b1[j].x, org[1], EDGE) && range_hits_span(b0[j].z, b1[j].y, org[2], EDGE);
                 const unsigned long long bal = __ballot(keep);             // one LDS atomic per wave, ranks from the ballot
                 uint32_t wb = 0;
                 if (lane == 0 && bal) wb = atomicAdd(&s_total, (uint32_t)__popcll(bal));
@@ -167,13 +180,13 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
                 if (keep) {
                     const uint32_t slot = wb + (uint32_t)__popcll(bal & lanemask_lt());
                     if (slot < CL_LIST) list[slot] = i;
-                    else cluster_add_votes(a, region, hits, box, i, 0u, 1u, org);   // list full: this thread takes the record alone
+                    else cluster_add_votes<EDGE>(a, region, hits, box, i, 0u, 1u, org);   // list full: this thread takes the record alone
                 }
             }
         }
         __syncthreads();
         const uint32_t np = min(s_total, (uint32_t)CL_LIST);
-        for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) cluster_add_votes(a, region, hits, box, list[k >> 4], k & 15u, 16u, org);
+        for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) cluster_add_votes<EDGE>(a, region, hits, box, list[k >> 4], k & 15u, 16u, org);
         __syncthreads();
     } else if (a.leaf_hits) {
         // Rotation votes depend only on the leaf (prediction.rs:601-636): the accumulator is
@@ -192,9 +205,9 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
                 if (l < c1 && lh[l]) {
                     const uint4 t2 = ((const uint4 *)(a.f.tpl + l))[2];
                     const uint32_t bl = t2.y, bh = t2.z;
-                    keep = bl != 0xFFFFFFFFu && range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG) &&
-                           range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG) &&
-                           range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG);
+                    keep = bl != 0xFFFFFFFFu && range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], EDGE) &&
+                           range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], EDGE) &&
+                           range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], EDGE);
                 }
                 const unsigned long long bal = __ballot(keep);             // one LDS atomic per wave, ranks from the ballot
                 uint32_t wb = 0;
@@ -214,7 +227,7 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
                     uint32_t dx = (b & 255u) - (uint32_t)org[0];
                     uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
                     uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
-                    if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
+                    if (dx < EDGE && dy < EDGE && dz < EDGE) atomicAdd(&region[(dx * EDGE + dy) * EDGE + dz], vm);
                 }
             }
             __syncthreads();
@@ -236,22 +249,25 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
             for (int j = 0; j < 2; ++j) {
                 const uint32_t bl = r[j].x, bh = r[j].y;
                 if (bl == 0xFFFFFFFFu) continue;
-                if (!range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], RG)) continue;
-                if (!range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], RG)) continue;
-                if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], RG)) continue;
+                if (!range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], EDGE)) continue;
+                if (!range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], EDGE)) continue;
+                if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], EDGE)) continue;
                 const uint32_t v = vv[j];
                 for (uint32_t q = r[j].z; q < r[j].z + (r[j].w & 0xffffu); ++q) {
                     const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                   // prediction.rs:635
                     uint32_t dx = (b & 255u) - (uint32_t)org[0];
                     uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
                     uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
-                    if (dx < RG && dy < RG && dz < RG) atomicAdd(&region[(dx * RG + dy) * RG + dz], vm);
+                    if (dx < EDGE && dy < EDGE && dz < EDGE) atomicAdd(&region[(dx * EDGE + dy) * EDGE + dz], vm);
                 }
             }
         }
     }
 }
 
+// SUP: the batch has blocks of both accumulators in global memory (k_region; a.pre_region != NULL); a separate instance so that
+// the code of batches without them keeps its registers.
+template <bool SUP>
 __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
     __shared__ uint32_t region[RG3];
     __shared__ __attribute__((aligned(16))) float prod[CL_PROD_CAP * 4];
@@ -264,7 +280,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
 
     const int which = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
 
-    const ClShared sh{region, prod, red64, red32, s_pos, &s_total};
+    const ClShared sh{prod, red64, red32, s_pos, &s_total};
     cl_initial_guess(a, which, frame, sh);
     __syncthreads();
     int32_t pos[3] = {s_pos[0], s_pos[1], s_pos[2]};
@@ -285,19 +301,37 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                  wo2 = (uint32_t)pos[2] - 10u - (uint32_t)org[2];
         if (!have_region || wo0 > RG - 20 || wo1 > RG - 20 || wo2 > RG - 20) {
             // ---- (re)build the region centred on the window
-            for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)pos[k] - 10u - (uint32_t)((RG - 20) / 2));
-            wo0 = wo1 = wo2 = (RG - 20) / 2;
             have_region = true;
             __syncthreads();                       // previous iteration's readers are done
-            if (a.pre_region && it == 0 && n_hits >= a.pre_min_hits) {
-                // the region around the initial guess was gathered by k_region (several workgroups per frame)
-                // (consumed and left zero again: the pre-gathered regions need no per-batch fill)
-                uint32_t *pr = a.pre_region + ((size_t)frame * 2 + which) * RG3;
-                for (int i = tid; i < RG3; i += CL_THREADS) { const uint32_t v = pr[i]; region[i] = v; if (v) pr[i] = 0; }
+            // k_region (several workgroups per frame) built the cells of both accumulators around the initial guess (s_pos still
+            // holds it): a region that holds the window and lies inside that block -- centred on the window where the block allows,
+            // pushed back inside it otherwise -- is cut out of the block; only a window that has left the block is gathered from
+            // the records (any region that holds the window gives the same sums: the region is a cache of the accumulator's cells)
+            const int32_t edge = which == 0 ? SRG : RRG, pad = which == 0 ? SPAD : RPAD;
+            int32_t dc[3];
+            uint32_t wo[3];
+            bool fits = SUP && n_hits >= a.pre_min_hits;
+            for (int k = 0; k < 3; ++k) {
+                // offset of the centred region's origin from the block's (garbage if the window is nowhere near: then nothing fits)
+                const int32_t d = (int32_t)((uint32_t)pos[k] - (uint32_t)s_pos[k] + (uint32_t)pad);
+                dc[k] = min(max(d, 0), edge - RG);
+                wo[k] = (uint32_t)d + (uint32_t)((RG - 20) / 2) - (uint32_t)dc[k];
+                fits = fits && wo[k] <= RG - 20;
+            }
+            if (fits) {
+                for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)s_pos[k] - 10u - (uint32_t)((RG - 20) / 2) - (uint32_t)pad + (uint32_t)dc[k]);
+                wo0 = wo[0]; wo1 = wo[1]; wo2 = wo[2];
+                const uint32_t *sup = a.pre_region + ((size_t)frame * 2 + which) * SRG3 + ((size_t)dc[0] * edge + dc[1]) * edge + dc[2];
+                for (int i = tid; i < RG3; i += CL_THREADS) {
+                    const uint32_t dz = (uint32_t)i % RG, dy = ((uint32_t)i / RG) % RG, dx = (uint32_t)i / (RG * RG);
+                    region[i] = sup[(dx * edge + dy) * edge + dz];
+                }
             } else {
+                for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)pos[k] - 10u - (uint32_t)((RG - 20) / 2));
+                wo0 = wo1 = wo2 = (RG - 20) / 2;
                 for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
                 __syncthreads();
-                cl_gather(a, which, frame, org, 0u, n_hits, 0u, a.f.n_leaves, sh);
+                cl_gather<RG>(a, which, frame, org, 0u, n_hits, 0u, a.f.n_leaves, sh, region);
             }
         }
         __syncthreads();
@@ -405,26 +439,32 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
 
 hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s) {
     if (a.n_frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_cluster, dim3(2, a.n_frames), dim3(CL_THREADS), 0, s, a);
+    if (a.pre_region) hipLaunchKernelGGL(k_cluster<true>, dim3(2, a.n_frames), dim3(CL_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_cluster<false>, dim3(2, a.n_frames), dim3(CL_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
 // ================================================================== k_region
-// The first region gather of k_cluster, spread over several workgroups per (frame, accumulator): with few frames in the
-// batch and many hit records per frame (large forests, stride 1-2: 60-90 k records per frame at BASELINE config 3) one
-// workgroup streaming a whole frame's records is the slowest thing in the step while most CUs idle.  Workgroup
-// (slice, frame, which) recomputes the initial guess (a few microseconds), gathers its share of the records (or leaves)
-// into an LDS region exactly as k_cluster would and adds its non-zero cells to the frame's pre-built region in global
-// memory (integer atomics: the sum over the slices is the region k_cluster would have built).
+// Small batches with many hit records per frame (large forests, stride 1-2: 60-90 k records per frame at BASELINE config 3):
+// one workgroup streaming a whole frame's records every time the mean-shift window leaves its 26^3 region is the slowest thing
+// in the step while most CUs idle.  Here several workgroups per (frame, accumulator) build, once, in global memory (zeroed per
+// batch by the host) the SRG^3 cells of the position accumulator and the RRG^3 cells of the rotation accumulator around the
+// initial guesses: workgroup (slice, frame) of accumulator WHICH recomputes the initial guess (a few microseconds) and adds the
+// votes of its share of the records (or leaves) that fall into the block, exactly as k_cluster's own gather would (integer
+// atomics: the sum over the slices is the reference's accumulator on those cells, prediction.rs:635, :667).  k_cluster then cuts
+// the regions it needs out of the blocks: on the config-3 workload the position window drifts a cell per iteration on some
+// frames (up to 18 cells in 20 iterations) and the rotation window up to 4 cells, and every 26^3 region a window outgrew used to
+// cost a scan of all the frame's records by one workgroup (0.55 ms of that step for one rotation rebuild).
+template <int WHICH>
 __global__ void __launch_bounds__(CL_THREADS, 8) k_region(ClusterArgs a) {
-    __shared__ uint32_t region[RG3];
+    extern __shared__ uint32_t block[];                             // WHICH == 1: [RRG3]
     __shared__ __attribute__((aligned(16))) float prod[CL_PROD_CAP * 4];
     __shared__ unsigned long long red64[CL_WAVES];
     __shared__ uint32_t red32[CL_WAVES];
     __shared__ int32_t s_pos[3];
     __shared__ uint32_t s_total;
-    const int slice = blockIdx.x, frame = blockIdx.y, which = blockIdx.z, tid = threadIdx.x;
-    const ClShared sh{region, prod, red64, red32, s_pos, &s_total};
+    const int slice = blockIdx.x, frame = blockIdx.y, which = WHICH, tid = threadIdx.x;
+    const ClShared sh{prod, red64, red32, s_pos, &s_total};
     uint32_t n_hits = a.hit_count[frame];
     if (n_hits > a.hits_cap) n_hits = a.hits_cap;
     if (n_hits < a.pre_min_hits) return;                            // few records: k_cluster gathers this frame's regions itself
@@ -438,23 +478,40 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_region(ClusterArgs a) {
     if (by_leaves ? l0 >= l1 : h0 >= h1) return;                    // nothing in this share (uniform for the workgroup)
     cl_initial_guess(a, which, frame, sh);
     __syncthreads();
+    uint32_t *pre = a.pre_region + ((size_t)frame * 2 + which) * SRG3;
     int32_t org[3];
-    for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)s_pos[k] - 10u - (uint32_t)((RG - 20) / 2));
-    for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
-    __syncthreads();
-    cl_gather(a, which, frame, org, h0, h1, l0, l1, sh);
-    __syncthreads();
-    uint32_t *pr = a.pre_region + ((size_t)frame * 2 + which) * RG3;
-    for (int i = tid; i < RG3; i += CL_THREADS) {
-        const uint32_t v = region[i];
-        if (v) atomicAdd(&pr[i], v);
+    if (WHICH == 0) {
+        // position votes: few of a frame's records reach the block and its cells are mostly empty: straight into global memory
+        for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)s_pos[k] - 10u - (uint32_t)((RG - 20) / 2) - (uint32_t)SPAD);
+        cl_gather<SRG>(a, which, frame, org, h0, h1, l0, l1, sh, pre);
+    } else {
+        // rotation votes are dense around the guess (every record of a frame reaches the block; as scattered global atomics
+        // they took 1.16 ms on BASELINE config 3 against 0.12 ms this way): gathered in LDS, then one coalesced flush of the
+        // non-zero cells
+        for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)s_pos[k] - 10u - (uint32_t)((RG - 20) / 2) - (uint32_t)RPAD);
+        for (int i = tid; i < RRG3; i += CL_THREADS) block[i] = 0;
+        __syncthreads();
+        cl_gather<RRG>(a, which, frame, org, h0, h1, l0, l1, sh, block);
+        __syncthreads();
+        for (int i = tid; i < RRG3; i += CL_THREADS) {
+            const uint32_t v = block[i];
+            if (v) atomicAdd(&pre[i], v);
+        }
     }
+}
+
+// (the rotation instance takes 128 KB of dynamic LDS: a per-device attribute, set with k_traverse's by dh_kernels_init)
+hipError_t dh_region_init() {
+    return hipFuncSetAttribute((const void *)k_region<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RRG3 * (int)sizeof(uint32_t));
 }
 
 hipError_t dh_launch_region(const ClusterArgs &a, hipStream_t s) {
     if (a.n_frames == 0 || a.iterations == 0 || !a.pre_region || a.pre_slices < 1) return hipSuccess;
     if (a.n_frames > 65535) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL(k_region, dim3(a.pre_slices, a.n_frames, 2), dim3(CL_THREADS), 0, s, a);
+    // (the rotation instance holds a CU's LDS alone; half as many, twice as long shares -- one round on the chip at 32 frames -- take
+    // 0.23 instead of 0.12 ms: the time goes with the length of a share; four of a record's cells in flight change nothing)
+    hipLaunchKernelGGL(k_region<1>, dim3(a.pre_slices, a.n_frames), dim3(CL_THREADS), RRG3 * sizeof(uint32_t), s, a);
+    hipLaunchKernelGGL(k_region<0>, dim3(a.pre_slices, a.n_frames), dim3(CL_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

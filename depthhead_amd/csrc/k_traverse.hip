@@ -774,6 +774,7 @@ hipError_t dh_kernels_init(int device) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_traverse<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = dh_region_init();
     if (e != hipSuccess) return e;
     if (tracked) done[device >> 6].fetch_or(1ull << (device & 63), std::memory_order_release);
     return hipSuccess;

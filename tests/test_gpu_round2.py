@@ -443,8 +443,8 @@ def test_general_path_patches_beyond_255_keep_the_division_walk(hp_mod, oracle):
 @pytest.mark.parametrize("min_hits", [None, "1", "100000000"])
 @pytest.mark.parametrize("leaf_hist", [True, False])
 def test_first_regions_gathered_by_k_region(hp_mod, oracle, leaf_hist, min_hits):
-    """Small batches with many hit records: k_region gathers the first mean-shift region of both accumulators with several
-    workgroups per frame and k_cluster starts from it.  Forced on for every frame (DH_REGION_MIN_HITS=1), off (huge
+    """Small batches with many hit records: k_region gathers the cells of both accumulators around the initial guesses with several
+    workgroups per frame and k_cluster cuts its regions out of them (tests/test_gpu_round3.py has the windows that travel).  Forced on for every frame (DH_REGION_MIN_HITS=1), off (huge
     threshold) and automatic, with and without the leaf histogram: identical traces and poses (integer atomics are order-free)."""
     forest = synth.fit_forest(8, 10, synth.FOREST_SEED_BASE + 61, n_frames=12, subset=1500)
     model = synth.ModelParams(stepwidth=2)
@@ -464,7 +464,7 @@ def test_first_regions_gathered_by_k_region(hp_mod, oracle, leaf_hist, min_hits)
         _check_frames(hp_mod, oracle, forest, model, frames[:3], synth.default_intrinsic(w, h),
                       rs.uniform(-100, 900, (3, 3)).astype(np.float32), rs.uniform(-1, 1, (3, 3)), np.array([3, 1, 2], dtype=np.uint8), full=False)
         _product_mode_check(hp_mod, oracle, forest, model, frames, synth.default_intrinsic(w, h))
-        # the pre-gathered regions are consumed and left zero by k_cluster (no per-batch fill): several batches of other frames
+        # the blocks are zeroed per batch: several batches of other frames
         # through ONE predictor, every pose against the oracle's
         K = synth.default_intrinsic(w, h)
         other = synth.biwi_batch(5, w, h, first=140)

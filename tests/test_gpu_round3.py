@@ -298,3 +298,41 @@ def test_profiling_changes_nothing_and_times_every_kernel(hp_mod, oracle):
     parts = [t[k] for k in ("boxsum_ms", "traverse_ms", "emit_ms", "vote_ms", "cluster_ms")]
     assert all(p > 0.0 for p in parts) and t["n_frames"] == 6
     assert abs(sum(parts) - t["total_ms"]) < 0.02 * t["total_ms"] + 1e-3
+
+
+# ------------------------------------------------------------------ k_region's blocks: windows that travel
+@pytest.mark.parametrize("leaf_hist", [True, False])
+def test_windows_that_travel_inside_and_beyond_the_blocks_of_k_region(hp_mod, oracle, leaf_hist):
+    """Small batches with many hit records: k_region builds 64^3 cells of the position accumulator and 32^3 of the rotation
+    accumulator around the initial guesses, and k_cluster cuts every 26^3 region it needs out of them -- centred on the window
+    while the block allows, pushed back inside it near its faces -- and gathers a region from the hit records again only once
+    the window has left the block.  A dense forest at stride 1 with 45 iterations (the position window drifts a cell per
+    iteration: 31 cells on the first frame) and rotation guesses 5 and 9 bins off take all three ways; every iteration of both
+    mean shifts against the oracle's trace, then the plain product path."""
+    from test_gpu_parity import _check_frames
+    forest = synth.synth_forest(16, 10, synth.FOREST_SEED_BASE + 3)
+    model = synth.ModelParams(stepwidth=1, meanshift_iterations=45)
+    w, h = 640, 480
+    K = synth.default_intrinsic(w, h)
+    frames = np.stack([synth.biwi_like(w, h, synth.FRAME_SEED_BASE + s) for s in (16, 12)])
+    base = [oracle.predict(forest, model, f, K) for f in frames]
+    rot = np.stack([base[0].rotation + np.array([5, 0, -5]) * 3.14159 / 60, base[1].rotation + np.array([-9, 0, 9]) * 3.14159 / 60])
+    mask = np.array([2, 2], dtype=np.uint8)                       # rotation guesses only: the position windows start at their own guess
+    ref = [oracle.predict(forest, model, frames[i], K, None, rot[i]) for i in range(2)]
+    travel = lambda tr: int(np.abs(np.asarray(tr, dtype=np.int64) - np.asarray(tr[0], dtype=np.int64)).max())
+    # the workload does what the test is for (block half-widths: 19 + 3 cells for the position, 3 + 3 for the rotation)
+    assert travel(ref[0].ms_trace_mid) > 22 and 3 < travel(ref[0].ms_trace_rot) <= 6 and travel(ref[1].ms_trace_rot) > 6
+    env = {"DH_REGION_MIN_HITS": "1"}
+    if not leaf_hist:
+        env["DH_NO_LEAF_HIST"] = "1"
+    os.environ.update(env)
+    try:
+        _check_frames(hp_mod, oracle, forest, model, frames, K, None, rot, mask, full=False)
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            for _ in range(2):                                    # the blocks are zeroed per batch
+                got = hp.predict_batch(frames, hp_mod.IntrinsicMatrix(K), None, rot, mask)
+                for i in range(2):
+                    assert np.array_equal(got["mid_point"][i], ref[i].mid_point) and np.array_equal(got["rotation"][i], ref[i].rotation)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
