@@ -103,7 +103,7 @@ struct dh_predictor {
     uint32_t n_trees = 0, n_nodes = 0, n_leaves = 0, n_off = 0, n_rot = 0, max_depth = 0;
     DevForest dev{};
     std::vector<void *> forest_allocs;
-    float *kern_ord = nullptr;   // device, 8000 floats
+    float *kern_r2 = nullptr;    // device, DH_KERN_R2 floats: the mean-shift kernel by squared distance
     uint16_t *zeros = nullptr;   // device, 64 zero bytes (k_boxsum reads them for columns right of the image)
     bool f_uniform = false;      // forest has one split-rectangle size
     int f_rw = 0, f_rh = 0;
@@ -213,9 +213,9 @@ static int upload(dh_predictor *p, const T **out, const std::vector<T> &v) {
 }
 
 static int build_kernel_table(dh_predictor *p) {
-    std::vector<float> k;
-    dh_build_kernel_table_(p->params.gaussian_sigma, k);    // get_or_build_kernel caches it per sigma (prediction.rs:310-317)
-    HIP_TRY(hipMemcpy(p->kern_ord, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> r2;
+    dh_build_kernel_r2_(p->params.gaussian_sigma, r2, DH_KERN_R2);    // get_or_build_kernel caches it per sigma (prediction.rs:310-317)
+    HIP_TRY(hipMemcpy(p->kern_r2, r2.data(), r2.size() * sizeof(float), hipMemcpyHostToDevice));
     return DH_OK;
 }
 
@@ -249,7 +249,7 @@ static int predictor_destroy_(dh_predictor *p) {
     drop_graph(p);
     free_workspace(p);
     for (void *q : p->forest_allocs) (void)hipFree(q);
-    if (p->kern_ord) (void)hipFree(p->kern_ord);
+    if (p->kern_r2) (void)hipFree(p->kern_r2);
     if (p->blur_kern) (void)hipFree(p->blur_kern);
     if (p->zeros) (void)hipFree(p->zeros);
     for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -342,7 +342,8 @@ static int predictor_build(dh_predictor *p, const dh_forest *f, const dh_params 
     STEP(dev_alloc(p, &d.rbin_box, p->n_leaves, true));
     STEP(dev_alloc(p, &d.rbin_box_hi, p->n_leaves, true));
     STEP(dev_alloc(p, &d.tpl, p->n_leaves, true));
-    STEP(dev_alloc(p, &p->kern_ord, DH_GRID3));
+    STEP(dev_alloc(p, &d.rot_dir, p->n_leaves, true));
+    STEP(dev_alloc(p, &p->kern_r2, DH_KERN_R2));
     STEP(dev_alloc(p, &p->zeros, 32));
     { uint4 *nu = nullptr; STEP(dev_alloc(p, &nu, p->n_nodes, true)); p->nodes_u = nu; }
     if (p->n_nodes > 0 && (size_t)p->n_nodes + p->n_leaves + 2 * DH_AMB_CAP < ((size_t)1 << 27) && !p->knobs.no_absorb) {   // (byte offsets into the table stay below 2^31)
@@ -662,10 +663,22 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ca.f = p->dev; ca.hits = p->hits + hoff; ca.hit_box = p->hit_box + hoff; ca.hit_rot = p->hit_rot + hoff;
         ca.hit_count = hit_count; ca.hits_cap = p->hits_cap;
         ca.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
-        ca.pos_grid = pos_grid; ca.rot_grid = rot_grid; ca.kern_ord = p->kern_ord;
+        ca.pos_grid = pos_grid; ca.rot_grid = rot_grid; ca.kern_r2 = p->kern_r2;
         ca.iterations = p->params.meanshift_iterations;
 #ifdef DH_PROFILING_KNOBS
         ca.stop = p->knobs.cl_stop;
+        static unsigned long long *cl_stamps = nullptr;
+        if (p->knobs.cl_stamps) {
+            if (!cl_stamps) { HIP_TRY(hipMalloc((void **)&cl_stamps, 128)); HIP_TRY(hipMemset(cl_stamps, 0, 128)); }
+            else {
+                unsigned long long hst[16];
+                HIP_TRY(hipMemcpy(hst, cl_stamps, 128, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[k_cluster rotation workgroups, cycles summed] guess=%llu zero=%llu gather=%llu | per sum: sweep=%llu scan=%llu park=%llu products=%llu chain=%llu update=%llu | sums=%llu workgroups=%llu\n",
+                        hst[0], hst[1], hst[2], hst[3], hst[4], hst[5], hst[6], hst[7], hst[8], hst[14], hst[15]);
+                HIP_TRY(hipMemset(cl_stamps, 0, 128));
+            }
+            ca.dbg_stamps = cl_stamps;
+        }
 #endif
         ca.midp_guess = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
         ca.rot_guess = rot_guess ? rot_guess + (size_t)f0 * 3 : nullptr;

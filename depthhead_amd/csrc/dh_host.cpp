@@ -200,6 +200,7 @@ Knobs dh_read_knobs_() {
     k.trav_stop = geti("DH_TRAV_STOP", 0); k.emit_stop = geti("DH_EMIT_STOP", 0);
     k.vote_stop = geti("DH_VOTE_STOP", 0); k.cl_stop = geti("DH_CL_STOP", 0);
     k.trav_stamps = getenv("DH_TRAV_STAMPS") != nullptr;
+    k.cl_stamps = getenv("DH_CL_STAMPS") != nullptr;
 #endif
     return k;
 }
@@ -367,6 +368,12 @@ void dh_build_kernel_table_(float sigma, std::vector<float> &k) {
                 int norm = dx * dx + dy * dy + dz * dz;
                 k[((size_t)x * G + y) * G + z] = expf(-1.0f * (float)norm / (2.0f * sigma));
             }
+}
+// The same weights by squared distance: kernel_function (meanshift.rs:228-232) sees only norm = dx^2 + dy^2 + dz^2, at most
+// 3 * 10^2, so 301 values are the whole kernel (k_cluster keeps them in LDS).
+void dh_build_kernel_r2_(float sigma, std::vector<float> &k, size_t padded) {
+    k.assign(padded, 0.0f);
+    for (int norm = 0; norm <= 300 && (size_t)norm < padded; ++norm) k[(size_t)norm] = expf(-1.0f * (float)norm / (2.0f * sigma));
 }
 
 // imageproc 0.12.0 filter::gaussian_kernel_f32(sigma) (crate source not in the container; PARITY UNPINNED): radius

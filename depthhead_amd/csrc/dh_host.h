@@ -92,6 +92,7 @@ struct Knobs {
     bool no_general_int = false;      // DH_NO_GENERAL_INT: general path with the f64 divisions on every visit
     int stage_chunk = 64;             // DH_STAGE_CHUNK: frames per upload chunk of the host entry points
     int host_threads = 8;             // DH_HOST_THREADS: host threads that validate / pack run-length coded payloads
+    bool cl_stamps = false;
     int trav_stop = 0, emit_stop = 0, vote_stop = 0, cl_stop = 0;   // (-DDH_PROFILING_KNOBS builds only)
     bool trav_stamps = false;
 };
@@ -132,6 +133,7 @@ static const int kBoxSpan = 256, kBoxMaxRect = 96;   // image columns one k_boxs
 
 // ------------------------------------------------------------------ small numeric tables (f32, no FMA: -ffp-contract=off)
 void dh_mat3_inv_f32_(const float m[9], float o[9]);                 // Mat3<f32>::inv (meancov_estimation.rs:339-352)
+void dh_build_kernel_r2_(float sigma, std::vector<float> &k, size_t padded);   // the same weights indexed by dx^2 + dy^2 + dz^2 (0 .. 300)
 void dh_build_kernel_table_(float sigma, std::vector<float> &k);    // FullArray3D::build_kernel(20, sigma) (meanshift.rs:228-252), summation order
 int dh_blur_taps_(float sigma, std::vector<float> &k);               // imageproc gaussian_kernel_f32 (restated; parity unpinned)
 

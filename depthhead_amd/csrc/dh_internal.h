@@ -11,6 +11,7 @@
 #define DH_POSGRID 400         // 20^2
 #define DH_ROTPARTS 120
 #define DH_REGION_CELLS (26 * 26 * 26)   // k_cluster's LDS region of an accumulator (RG^3 in k_cluster.hip)
+#define DH_KERN_R2 304                    // Gaussian weights by squared distance 0 .. 300 (the 20^3 kernel holds 301 distinct values), padded
 #define DH_SUPER_CELLS (64 * 64 * 64)    // k_region's block of an accumulator in global memory (SRG^3 in k_cluster.hip)
 
 // leaf_flags bits (written by k_leaf_prepare)
@@ -58,6 +59,8 @@ struct DevForest {
     uint32_t *rbin_box;    // per leaf: component-wise minimum of its rotation bins, r1 | r2<<8 | r3<<16
     uint32_t *rbin_box_hi; // per leaf: component-wise maximum, same packing
     struct LeafTpl *tpl;   // per leaf: everything a hit record needs, one 64-byte line
+    uint4 *rot_dir;        // per leaf: {rbin_box (0xFFFFFFFF: no rotation votes), rbin_box_hi, rot_begin, distinct fine bins}: what the mean shift's
+                           // gather by leaves needs of a leaf, in one load
 };
 
 // One (gated patch, voting leaf) pair = three self-contained 16/32-byte records, so that neither the
@@ -210,7 +213,8 @@ struct ClusterArgs {
     const uint32_t *leaf_hits; // nullable [n_frames][n_leaves], see TraverseArgs
     const uint32_t *pos_grid;
     const uint32_t *rot_grid;
-    const float    *kern_ord;  // 8000 floats, index (dx*20+dy)*20+dz = summation order (meanshift.rs:344-346)
+    const float    *kern_r2;   // DH_KERN_R2 floats: the 20^3 Gaussian kernel by squared distance dx^2 + dy^2 + dz^2 (kernel_function takes nothing
+                               // else, meanshift.rs:228-232; FullArray3D::build_kernel, :244-252)
     uint32_t  iterations;
     const float   *midp_guess; // nullable, n*3
     const double  *rot_guess;  // nullable, n*3
@@ -219,10 +223,11 @@ struct ClusterArgs {
     uint32_t *pre_region;      // nullable [n][2][64^3]: the accumulators' cells around the initial guesses, gathered by k_region (zeroed per batch)
     int       pre_slices;      // workgroups per (frame, accumulator) of k_region
     uint32_t  pre_min_hits;    // frames with fewer hit records are left to k_cluster alone (both kernels read the same count)
+    unsigned long long *dbg_stamps; // profiling twin (env DH_CL_STAMPS): [16] summed cycles per phase of the rotation workgroups
     int32_t  *dbg_guess;       // nullable [n][6]
     int32_t  *dbg_trace;       // nullable [2][n][iterations+1][3]
     uint32_t *dbg_steps;       // nullable [2][n]
-    int stop;               // profiling knob (env DH_CL_STOP): 1 / 2 / 3 = return after the initial guess / the first region build / the first weighted sum
+    int stop;               // profiling knob (env DH_CL_STOP): low 4 bits 1 / 2 / 3 = return after the initial guess / the first region build / the first weighted sum; + 16 / 32: the position / rotation workgroups return at once
 };
 
 struct VotesDumpArgs {

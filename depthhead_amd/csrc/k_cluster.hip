@@ -195,39 +195,87 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
         // hits * v * mult the same residue as that many separate adds.
         const uint32_t *lh = a.leaf_hits + (size_t)frame * a.f.n_leaves;
         uint32_t *list = (uint32_t *)prod;                    // same two-step scheme as the position gather
-        for (uint32_t c0 = l0; c0 < l1; c0 += CL_LIST) {
+        // Two steps, like the position gather: (1) the leaves that voted and whose cells can reach the block are listed -- a thread's
+        // four histogram loads (leaves tid, tid + 1024, ...) are in flight together, then the four directory entries {bounding
+        // box, first cell, cells} of those that voted: two round trips per 4096 leaves; (2) eight lanes share each listed leaf and
+        // take its cells eight apart, and a thread has four such (leaf, eighth) items in flight: directory entry, valtoadd and
+        // histogram count of all four in one round trip, their cells in the next.  What a lane pays for here is the number of
+        // DEPENDENT round trips (bench workload: ~1 000 listed leaves of ~10 cells; one item after the other, sixteen lanes per
+        // leaf and the leaf's template fetched per item were ~32 round trips per thread: 0.023 of k_cluster's 0.059 ms).
+        // A leaf that finds the list full is handled by its thread at once.
+        auto leaf_alone = [&](const uint32_t l, const uint4 d) {
+            const uint32_t v = lh[l] * a.f.leaf_v[l];                        // times the leaf voted x valtoadd
+            for (uint32_t q = d.z; q < d.z + d.w; ++q) {
+                const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                      // prediction.rs:635
+                uint32_t dx = (b & 255u) - (uint32_t)org[0];
+                uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
+                uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
+                if (dx < EDGE && dy < EDGE && dz < EDGE) atomicAdd(&region[(dx * EDGE + dy) * EDGE + dz], vm);
+            }
+        };
+        constexpr uint32_t LR = 4, LL = 8, LI = 4;                             // leaves per thread and scan round; lanes per listed leaf; items in flight
+        for (uint32_t c0 = l0; c0 < l1; c0 += LR * CL_THREADS) {
             if (tid == 0) s_total = 0;
             __syncthreads();
-            const uint32_t c1 = min(l1, c0 + CL_LIST);
-            for (uint32_t l0 = c0; l0 < c1; l0 += CL_THREADS) {          // (uniform trip count: the ballot needs every lane)
-                const uint32_t l = l0 + tid;
-                bool keep = false;
-                if (l < c1 && lh[l]) {
-                    const uint4 t2 = ((const uint4 *)(a.f.tpl + l))[2];
-                    const uint32_t bl = t2.y, bh = t2.z;
-                    keep = bl != 0xFFFFFFFFu && range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], EDGE) &&
-                           range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], EDGE) &&
-                           range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], EDGE);
-                }
+            uint32_t cnt[LR];
+            uint4 d[LR];
+#pragma unroll
+            for (uint32_t r = 0; r < LR; ++r) { const uint32_t l = c0 + r * CL_THREADS + tid; cnt[r] = l < l1 ? lh[l] : 0u; }
+#pragma unroll
+            for (uint32_t r = 0; r < LR; ++r) {
+                d[r] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+                if (cnt[r]) d[r] = a.f.rot_dir[c0 + r * CL_THREADS + tid];
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < LR; ++r) {                                // (uniform trip count: the ballot needs every lane)
+                const uint32_t l = c0 + r * CL_THREADS + tid, bl = d[r].x, bh = d[r].y;
+                const bool keep = bl != 0xFFFFFFFFu && range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], EDGE) &&
+                                  range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], EDGE) &&
+                                  range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], EDGE);
                 const unsigned long long bal = __ballot(keep);             // one LDS atomic per wave, ranks from the ballot
                 uint32_t wb = 0;
                 if (lane == 0 && bal) wb = atomicAdd(&s_total, (uint32_t)__popcll(bal));
                 wb = __shfl(wb, 0);
-                if (keep) list[wb + (uint32_t)__popcll(bal & lanemask_lt())] = l;
+                if (keep) {
+                    const uint32_t slot = wb + (uint32_t)__popcll(bal & lanemask_lt());
+                    if (slot < CL_LIST) list[slot] = l;
+                    else leaf_alone(l, d[r]);
+                }
             }
             __syncthreads();
-            const uint32_t np = s_total;
-            for (uint32_t k = tid; k < np * 16u; k += CL_THREADS) {
-                const uint32_t l = list[k >> 4], sub = k & 15u;
-                const uint4 *tp = (const uint4 *)(a.f.tpl + l);
-                const uint4 t1 = tp[1], t2 = tp[2], t3 = tp[3];
-                const uint32_t v = lh[l] * t1.z, q1 = t2.w + (t3.x & 0xffffu);   // times the leaf voted x valtoadd
-                for (uint32_t q = t2.w + sub; q < q1; q += 16u) {
-                    const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                  // prediction.rs:635
-                    uint32_t dx = (b & 255u) - (uint32_t)org[0];
-                    uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
-                    uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
-                    if (dx < EDGE && dy < EDGE && dz < EDGE) atomicAdd(&region[(dx * EDGE + dy) * EDGE + dz], vm);
+            if (KNOB_STOP((a.stop & 15) == 5)) return;
+            const uint32_t items = min(s_total, (uint32_t)CL_LIST) * LL;
+            for (uint32_t k0 = tid; k0 < items; k0 += LI * CL_THREADS) {
+                uint32_t q[LI], q1[LI], vm[LI];
+                {
+                    uint4 e[LI];
+                    uint32_t hc[LI], lv[LI];
+#pragma unroll
+                    for (uint32_t u = 0; u < LI; ++u) {
+                        const uint32_t k = k0 + u * CL_THREADS, l = list[(k < items ? k : k0) / LL];
+                        e[u] = a.f.rot_dir[l]; hc[u] = lh[l]; lv[u] = a.f.leaf_v[l];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < LI; ++u) {
+                        const uint32_t k = k0 + u * CL_THREADS;
+                        q[u] = e[u].z + (k & (LL - 1u)); q1[u] = k < items ? e[u].z + e[u].w : 0u; vm[u] = hc[u] * lv[u];
+                    }
+                }
+                for (;;) {
+                    uint32_t b[LI], mu[LI];
+#pragma unroll
+                    for (uint32_t u = 0; u < LI; ++u) { const uint32_t qq = q[u] < q1[u] ? q[u] : 0u; b[u] = a.f.rot_bin[qq]; mu[u] = a.f.rot_mult[qq]; }
+                    bool more = false;
+#pragma unroll
+                    for (uint32_t u = 0; u < LI; ++u) {
+                        uint32_t dx = (b[u] & 255u) - (uint32_t)org[0];
+                        uint32_t dy = ((b[u] >> 8) & 255u) - (uint32_t)org[1];
+                        uint32_t dz = ((b[u] >> 16) & 255u) - (uint32_t)org[2];
+                        if (q[u] < q1[u] && dx < EDGE && dy < EDGE && dz < EDGE) atomicAdd(&region[(dx * EDGE + dy) * EDGE + dz], vm[u] * mu[u]);   // prediction.rs:635
+                        q[u] += LL;
+                        more = more || q[u] < q1[u];
+                    }
+                    if (!more) break;
                 }
             }
             __syncthreads();
@@ -265,6 +313,17 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
     }
 }
 
+#ifdef DH_PROFILING_KNOBS
+#define CSTAMP(k)                                                                               \
+    if (a.dbg_stamps && which == 1 && tid == 0) {                                               \
+        unsigned long long t_ = clock64();                                                      \
+        atomicAdd(&a.dbg_stamps[k], t_ - t_prev);                                                \
+        t_prev = t_;                                                                            \
+    }
+#else
+#define CSTAMP(k)
+#endif
+
 // SUP: the batch has blocks of both accumulators in global memory (k_region; a.pre_region != NULL); a separate instance so that
 // the code of batches without them keeps its registers.
 template <bool SUP>
@@ -277,18 +336,26 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
     __shared__ int32_t s_pos[3];
     __shared__ float s_acc[4];
     __shared__ uint32_t s_total;
+    __shared__ float s_kr2[DH_KERN_R2];     // Gaussian weights by squared distance: no global load inside a weighted sum
 
     const int which = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
 
     const ClShared sh{prod, red64, red32, s_pos, &s_total};
+    if (tid < DH_KERN_R2) s_kr2[tid] = a.kern_r2[tid];        // (visible after the barriers of the initial guess)
+    if (KNOB_STOP((a.stop >> 4) == which + 1)) return;          // (profiling twin: DH_CL_STOP = 16 / 32 skips one accumulator)
+#ifdef DH_PROFILING_KNOBS
+    unsigned long long t_prev = a.dbg_stamps ? clock64() : 0ull;
+    if (a.dbg_stamps && which == 1 && tid == 0) atomicAdd(&a.dbg_stamps[15], 1ull);
+#endif
     cl_initial_guess(a, which, frame, sh);
     __syncthreads();
+    CSTAMP(0)
     int32_t pos[3] = {s_pos[0], s_pos[1], s_pos[2]};
     if (a.dbg_guess && tid < 3) a.dbg_guess[(size_t)frame * 6 + which * 3 + tid] = pos[tid];
     int32_t *trace = a.dbg_trace ? a.dbg_trace + ((size_t)which * a.n_frames + frame) * (a.iterations + 1) * 3 : nullptr;
     if (trace && tid < 3) trace[tid] = pos[tid];
 
-    if (KNOB_STOP(a.stop == 1)) return;
+    if (KNOB_STOP((a.stop & 15) == 1)) return;
     // ---------------- mean shift (meanshift.rs:328-407)
     uint32_t n_hits = a.hit_count[frame];
     if (n_hits > a.hits_cap) n_hits = a.hits_cap;
@@ -331,11 +398,14 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                 wo0 = wo1 = wo2 = (RG - 20) / 2;
                 for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
                 __syncthreads();
+                CSTAMP(1)
+                if (KNOB_STOP((a.stop & 15) == 4)) return;
                 cl_gather<RG>(a, which, frame, org, 0u, n_hits, 0u, a.f.n_leaves, sh, region);
             }
         }
         __syncthreads();
-        if (KNOB_STOP(a.stop == 2)) return;
+        CSTAMP(2)
+        if (KNOB_STOP((a.stop & 15) == 2)) return;
         // ---- order-preserving compaction of the window's non-zero cells; window cell index
         // (dx*20+dy)*20+dz = chunk*1024 + tid is the reference's summation order
 #pragma unroll 1
@@ -350,6 +420,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             if (lane == 0) cnt[c * CL_WAVES + wave] = (uint32_t)__popcll(b);
         }
         __syncthreads();
+        CSTAMP(3)
         if (wave == 0) {   // exclusive scan of the 128 (chunk, wave) counts, 2 per lane
             uint32_t c0 = cnt[lane * 2], c1 = cnt[lane * 2 + 1];
             uint32_t incl = c0 + c1;
@@ -360,6 +431,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             if (lane < 4) s_acc[lane] = 0.0f;
         }
         __syncthreads();
+        CSTAMP(4)
         const uint32_t total = s_total;
         for (uint32_t base = 0; base < total; base += CL_PROD_CAP) {
 #pragma unroll 1
@@ -375,12 +447,14 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                 }
             }
             __syncthreads();
-            {   // one thread per parked cell: Gaussian weight (one global load, all in flight together) and products, in place
+            CSTAMP(5)
+            {   // one thread per parked cell: Gaussian weight (by squared distance, from LDS) and products, in place
                 const uint32_t m = min((uint32_t)CL_PROD_CAP, total - base);
                 if ((uint32_t)tid < m) {
                     const uint2 cf = *(const uint2 *)(prod + tid * 4);
                     const uint32_t cell = cf.x, dz = cell % 20u, dy = (cell / 20u) % 20u, dx = cell / 400u;
-                    float w = __fmul_rn(a.kern_ord[cell], (float)cf.y);                     // meanshift.rs:370-379
+                    const int32_t ex = (int32_t)dx - 10, ey = (int32_t)dy - 10, ez = (int32_t)dz - 10;
+                    float w = __fmul_rn(s_kr2[ex * ex + ey * ey + ez * ez], (float)cf.y);   // meanshift.rs:228-232, :370-379
                     float ax = (float)(int32_t)((uint32_t)pos[0] + dx - 10u);               // :373-375
                     float ay = (float)(int32_t)((uint32_t)pos[1] + dy - 10u);
                     float az = (float)(int32_t)((uint32_t)pos[2] + dz - 10u);
@@ -388,6 +462,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                 }
             }
             __syncthreads();
+            CSTAMP(6)
             if (tid < 4) {   // the sequential chain: acc = acc + prod[i], in cell order
                 float acc = s_acc[tid];
                 uint32_t m = min((uint32_t)CL_PROD_CAP, total - base);
@@ -403,8 +478,9 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
                 s_acc[tid] = acc;
             }
             __syncthreads();
+            CSTAMP(7)
         }
-        if (KNOB_STOP(a.stop == 3)) return;
+        if (KNOB_STOP((a.stop & 15) == 3)) return;
         const float den = s_acc[3];
         if (den == 0.0f) break;                                                              // :385-388
         int32_t np0 = f32_as_i32(__fdiv_rn(s_acc[0], den)), np1 = f32_as_i32(__fdiv_rn(s_acc[1], den)),
@@ -412,6 +488,10 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
         const bool fixed = np0 == pos[0] && np1 == pos[1] && np2 == pos[2];
         pos[0] = np0; pos[1] = np1; pos[2] = np2;
         steps++;
+#ifdef DH_PROFILING_KNOBS
+        if (a.dbg_stamps && which == 1 && tid == 0) atomicAdd(&a.dbg_stamps[14], 1ull);
+#endif
+        CSTAMP(8)
         if (trace && tid < 3) trace[steps * 3 + tid] = pos[tid];
         if (fixed) {
             // a fixed point: every remaining iteration sees the same window and returns the same

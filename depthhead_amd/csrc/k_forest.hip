@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(256) k_leaf_prepare(DevForest f) {
     t.rlo = (flags & LF_ROT) ? f.rbin_box[L] : 0xFFFFFFFFu; t.rhi = f.rbin_box_hi[L];
     t.rb = rb; t.n_rot = n_fine | (n_rough << 16); t.flags = t.fc & 0xffu; t.prob = prob;
     f.tpl[L] = t;
+    f.rot_dir[L] = make_uint4(t.rlo, t.rhi, rb, n_fine);
 }
 
 hipError_t dh_launch_leaf_prepare(const DevForest &f, hipStream_t s) {

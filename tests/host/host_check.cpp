@@ -356,6 +356,17 @@ static void test_tables_and_knobs() {
     std::vector<float> k;
     dh_build_kernel_table_(8.0f, k);
     CHECK(k.size() == 8000 && k[(10 * 20 + 10) * 20 + 10] == 1.0f && k[0] > 0.0f && k[0] < 1e-7f);
+    // the table by squared distance (what k_cluster keeps in LDS) holds the same bits as every cell of the 20^3 kernel
+    for (float sigma : {8.0f, 0.37f, 1234.5f}) {
+        std::vector<float> full, r2;
+        dh_build_kernel_table_(sigma, full);
+        dh_build_kernel_r2_(sigma, r2, 304);
+        CHECK(r2.size() == 304);
+        for (int x = 0; x < 20; ++x) for (int y = 0; y < 20; ++y) for (int z = 0; z < 20; ++z) {
+            const int n = (x - 10) * (x - 10) + (y - 10) * (y - 10) + (z - 10) * (z - 10);
+            CHECK(n <= 300 && memcmp(&full[((size_t)x * 20 + y) * 20 + z], &r2[(size_t)n], 4) == 0);
+        }
+    }
     CHECK(dh_blur_taps_(8.0f, k) == DH_OK && k.size() == 33 && k[16] > k[15] && k[0] == k[32]);
     CHECK(dh_blur_taps_(0.0f, k) == DH_EINVAL && dh_blur_taps_(5000.0f, k) == DH_ESIZE);
     const float m[9] = {560, 0, 320, 0, 560, 240, 0, 0, 1};
