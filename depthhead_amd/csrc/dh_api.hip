@@ -673,7 +673,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
             else {
                 unsigned long long hst[16];
                 HIP_TRY(hipMemcpy(hst, cl_stamps, 128, hipMemcpyDeviceToHost));
-                fprintf(stderr, "[k_cluster rotation workgroups, cycles summed] guess=%llu zero=%llu gather=%llu | per sum: sweep=%llu scan=%llu park=%llu products=%llu chain=%llu update=%llu | sums=%llu workgroups=%llu\n",
+                fprintf(stderr, "[k_cluster rotation workgroups, cycles summed] guess=%llu zero=%llu gather=%llu | sums: count sweep=%llu (4)=%llu scan+park=%llu (6)=%llu chain=%llu update=%llu | sums=%llu workgroups=%llu\n",
                         hst[0], hst[1], hst[2], hst[3], hst[4], hst[5], hst[6], hst[7], hst[8], hst[14], hst[15]);
                 HIP_TRY(hipMemset(cl_stamps, 0, 128));
             }

@@ -14,8 +14,6 @@ OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-python3 "$REPO/bench.py" --steps 20 --warmup 3 $EXTRA > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
-echo "bench done"
 # Per-kernel durations: ONE batch in flight (--pipeline 1), so that a launch's duration is that kernel's own time -- the figure
 # bench.py's roofline uses (its HIP-event pass also runs one predictor alone).  With the default four batches in flight
 # kernels of consecutive batches share the chip and every launch takes longer while two run at once; that trace is kept
@@ -70,3 +68,9 @@ json.dump(sq, open(f"{out}/{tag}_sq_summary.json", "w"), indent=1, sort_keys=Tru
 for k, v in sorted(sq.items()):
     if k != "_meta": print(k, v)
 PY
+# the bench line once more, now that the counters of THIS build exist: bench.py prints roofline.traffic only from a summary whose
+# source hash matches the sources it runs (the copy in profiles/ here is the box's scratch copy; commit the one merged into gpurun_out/)
+cp "$OUT/${TAG}_pmc_summary.json" "$OUT/${TAG}_sq_summary.json" "$REPO/profiles/"
+cd /tmp
+python3 "$REPO/bench.py" --steps 20 --warmup 3 $EXTRA > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+echo "bench (with traffic) done"
