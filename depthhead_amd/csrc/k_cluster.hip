@@ -85,10 +85,13 @@ __device__ __forceinline__ void cl_initial_guess(const ClusterArgs &a, const int
         const uint32_t *g = which == 0 ? a.pos_grid + (size_t)frame * DH_POSGRID : a.rot_grid + (size_t)frame * DH_GRID3;
         const int ncell = which == 0 ? DH_POSGRID : DH_GRID3;
         unsigned long long best = 0;   // (value << 32) | ~idx
-        for (int i = tid; i < ncell; i += CL_THREADS) {
-            uint32_t gv = g[i];
-            unsigned long long k = ((unsigned long long)gv << 32) | (uint32_t)(~(uint32_t)i);
-            if (gv && k > best) best = k;
+        uint32_t gv[(DH_GRID3 + CL_THREADS - 1) / CL_THREADS];          // a thread's eight cells of the 20^3 grid: all loads in flight, one round trip
+#pragma unroll
+        for (int j = 0; j < (DH_GRID3 + CL_THREADS - 1) / CL_THREADS; ++j) { const int i = tid + j * CL_THREADS; gv[j] = i < ncell ? g[i] : 0u; }
+#pragma unroll
+        for (int j = 0; j < (DH_GRID3 + CL_THREADS - 1) / CL_THREADS; ++j) {
+            const unsigned long long k = ((unsigned long long)gv[j] << 32) | (uint32_t)(~(uint32_t)(tid + j * CL_THREADS));
+            if (gv[j] && k > best) best = k;
         }
         for (int d = WAVE / 2; d; d >>= 1) { unsigned long long o = __shfl_down(best, d); if (o > best) best = o; }
         if (lane == 0) red64[wave] = best;
@@ -342,6 +345,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
 
     const ClShared sh{prod, red64, red32, s_pos, &s_total};
     if (tid < DH_KERN_R2) s_kr2[tid] = a.kern_r2[tid];        // (visible after the barriers of the initial guess)
+    for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;   // (likewise: the first gather finds its region zeroed)
     if (KNOB_STOP((a.stop >> 4) == which + 1)) return;          // (profiling twin: DH_CL_STOP = 16 / 32 skips one accumulator)
 #ifdef DH_PROFILING_KNOBS
     __shared__ unsigned long long s_st[16];                     // cycles per phase, thread 0 of the rotation workgroups; flushed at the end
@@ -362,7 +366,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
     uint32_t n_hits = a.hit_count[frame];
     if (n_hits > a.hits_cap) n_hits = a.hits_cap;
     int32_t org[3] = {0, 0, 0};     // region origin (cell coordinates of region[0])
-    bool have_region = false;
+    bool have_region = false, clean = true;   // clean: the region holds zeros (from the start; not after a gather)
     uint32_t steps = 0;
     for (uint32_t it = 0; it < a.iterations; ++it) {
         // window offset inside the region; the region is valid while 0 <= woff <= RG-20 on every axis
@@ -390,6 +394,7 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             if (fits) {
                 for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)s_pos[k] - 10u - (uint32_t)((RG - 20) / 2) - (uint32_t)pad + (uint32_t)dc[k]);
                 wo0 = wo[0]; wo1 = wo[1]; wo2 = wo[2];
+                clean = false;
                 const uint32_t *sup = a.pre_region + ((size_t)frame * 2 + which) * SRG3 + ((size_t)dc[0] * edge + dc[1]) * edge + dc[2];
                 for (int i = tid; i < RG3; i += CL_THREADS) {
                     const uint32_t dz = (uint32_t)i % RG, dy = ((uint32_t)i / RG) % RG, dx = (uint32_t)i / (RG * RG);
@@ -398,8 +403,11 @@ __global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
             } else {
                 for (int k = 0; k < 3; ++k) org[k] = (int32_t)((uint32_t)pos[k] - 10u - (uint32_t)((RG - 20) / 2));
                 wo0 = wo1 = wo2 = (RG - 20) / 2;
-                for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
-                __syncthreads();
+                if (!clean) {
+                    for (int i = tid; i < RG3; i += CL_THREADS) region[i] = 0;
+                    __syncthreads();
+                }
+                clean = false;
                 CSTAMP(1)
                 if (KNOB_STOP((a.stop & 15) == 4)) return;
                 cl_gather<RG>(a, which, frame, org, 0u, n_hits, 0u, a.f.n_leaves, sh, region);
