@@ -198,6 +198,7 @@ struct VoteArgs {
     int stop;               // profiling knob (env DH_VOTE_STOP): 1 / 2 / 3 = return after the LDS set-up / the hit records / the leaf histogram
     int cell_fast;          // w and h are multiples of 20: a vote's guess-grid cell may be taken from an approximate quotient (vote_positions)
     float sx, sy;           // 20 / w, 20 / h
+    float kxs, cxs, kys, cys; // pinhole intrinsics: fx * sx, cx * sx, fy * sy, cy * sy (k_vote's approximate cell quotient)
 };
 
 struct ClusterArgs {

@@ -40,29 +40,38 @@ __device__ __forceinline__ void vote_positions(const VoteArgs &a, uint32_t *pos,
             if (o0 + VOTE_SUB * j >= oe) break;
             float nx = __fsub_rn(rec.x, ox[j]), ny = __fsub_rn(rec.y, oy[j]), nz = __fsub_rn(rec.z, oz[j]); // :647
             if (nz < 0.0f) continue;                                              // :650
-            float r[3];
-            if (PINNED) {
-                r[0] = __fadd_rn(__fmul_rn(nx, a.k[0]), __fmul_rn(nz, a.k[2]));
-                r[1] = __fadd_rn(__fmul_rn(ny, a.k[4]), __fmul_rn(nz, a.k[5]));
-                r[2] = __fadd_rn(nz, 0.0f);                                       // (x * 0 + y * 0) + z * 1: -0 becomes +0
-            } else {
-                matvec3(a.k, nx, ny, nz, r);                                      // types.rs:425
-            }
             // Only the CELL of the 20 x 20 grid is needed here.  When w and h are multiples of 20 (cells are whole pixels wide)
             // the cell of the reference's clamped, truncated quotient x2 (:662-672) is floor(clamp(x2 * 20 / w)), and an
-            // approximate quotient decides it whenever it is not next to a cell border: with v_rcp_f32 (1 ulp) and three more
-            // roundings u~ = (r0 * rcp(r2)) * (20 / w) is within 2.5 * 2^-23 * |u| < 7e-6 of the real u for |u| <= 21, the
-            // reference's own rounding of r0 / r2 moves it by < 2e-6 more, and outside [0, 20) both sides clamp into cell 0 / 19
-            // wherever they are.  Quotients within 1e-4 of an integer, and everything not finite (r2 = 0, NaN), take the two
-            // IEEE divisions -- 0.04 % of the votes.  Saves 22 of the 52 VALU instructions of a vote.
+            // approximate quotient decides it whenever it is not next to a cell border.  Pinhole intrinsics: u = x2 * 20 / w =
+            // (nx / nz) * (fx * 20 / w) + cx * 20 / w, taken as fma(nx * rcp(nz), kxs, cxs) with the two constants rounded once on
+            // the host: v_rcp_f32 (1 ulp), three roundings and the two constants put it within 9.2e-6 of the real u for |u| <= 21
+            // (|first term| <= 31), the reference's own four roundings move its quotient by < 7.4e-6 more, and outside [0, 20) both
+            // sides clamp into cell 0 / 19 wherever they are.  Quotients within 1e-4 of an integer, and everything not finite
+            // (nz = 0, NaN), take the reference's expression and its two IEEE divisions -- 0.04 % of the votes.
             uint32_t idx;
-            const float rc = __builtin_amdgcn_rcpf(r[2]);
-            const float ux = __fmul_rn(__fmul_rn(r[0], rc), a.sx), uy = __fmul_rn(__fmul_rn(r[1], rc), a.sy);
+            float ux, uy;
+            if (PINNED) {
+                const float rc = __builtin_amdgcn_rcpf(nz);
+                ux = __builtin_fmaf(__fmul_rn(nx, rc), a.kxs, a.cxs); uy = __builtin_fmaf(__fmul_rn(ny, rc), a.kys, a.cys);
+            } else {
+                float r[3];
+                matvec3(a.k, nx, ny, nz, r);                                      // types.rs:425
+                const float rc = __builtin_amdgcn_rcpf(r[2]);
+                ux = __fmul_rn(__fmul_rn(r[0], rc), a.sx); uy = __fmul_rn(__fmul_rn(r[1], rc), a.sy);
+            }
             const bool near_border = !(fabsf(__fsub_rn(ux, rintf(ux))) > 1.0e-4f) || !(fabsf(__fsub_rn(uy, rintf(uy))) > 1.0e-4f);
             if (a.cell_fast && !near_border) {
                 const float cxf = fminf(fmaxf(ux, 0.0f), 19.5f), cyf = fminf(fmaxf(uy, 0.0f), 19.5f);
                 idx = (uint32_t)cyf * DH_GRID + (uint32_t)cxf;
             } else {
+                float r[3];
+                if (PINNED) {
+                    r[0] = __fadd_rn(__fmul_rn(nx, a.k[0]), __fmul_rn(nz, a.k[2]));
+                    r[1] = __fadd_rn(__fmul_rn(ny, a.k[4]), __fmul_rn(nz, a.k[5]));
+                    r[2] = __fadd_rn(nz, 0.0f);                                   // (x * 0 + y * 0) + z * 1: -0 becomes +0
+                } else {
+                    matvec3(a.k, nx, ny, nz, r);                                  // types.rs:425
+                }
                 float qx = __fdiv_rn(r[0], r[2]), qy = __fdiv_rn(r[1], r[2]);
                 float x2 = qx > 0.0f ? qx : 0.0f; x2 = x2 < wm1 ? x2 : wm1;           // :662
                 float y2 = qy > 0.0f ? qy : 0.0f; y2 = y2 < hm1 ? y2 : hm1;           // :663
@@ -171,6 +180,7 @@ hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
     VoteArgs b = a;
     b.cell_fast = a.cell_fast && a.w % DH_GRID == 0 && a.h % DH_GRID == 0 && a.w > 0 && a.h > 0;
     b.sx = (float)DH_GRID / (float)a.w; b.sy = (float)DH_GRID / (float)a.h;
+    b.kxs = a.k[0] * b.sx; b.cxs = a.k[2] * b.sx; b.kys = a.k[4] * b.sy; b.cys = a.k[5] * b.sy;   // (one f32 rounding each: see vote_positions)
     if (a.w <= VOTE_TAB && a.h <= VOTE_TAB) {
         if (pin) hipLaunchKernelGGL((k_vote<true, true>), grid, block, 0, s, b);
         else hipLaunchKernelGGL((k_vote<true, false>), grid, block, 0, s, b);
