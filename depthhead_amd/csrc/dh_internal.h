@@ -50,8 +50,8 @@ struct DevForest {
     uint8_t  *leaf_flags;  // LF_*
     // rotation votes depend only on the leaf, and a leaf's votes fall into few distinct cells: each
     // leaf's slice [rot_begin, rot_begin + n) of these arrays holds its DISTINCT cells + multiplicities
-    uint32_t *rot_bin;     // distinct fine bins r1 | r2<<8 | r3<<16      (:605-627)
-    uint16_t *rot_mult;    // votes per distinct fine bin
+    uint32_t *rot_bin;     // distinct fine bins r1 | r2<<8 | r3<<16 | votes<<24 (:605-627; a bin with more than 255 votes: several entries)
+    uint16_t *rot_mult;    // (k_leaf_prepare's scratch: votes per distinct fine bin before they move into rot_bin's top byte)
     uint16_t *rot_rough;   // distinct indices into the 20^3 guess grid   (:630-636)
     uint16_t *rough_mult;  // votes per distinct guess-grid cell
     float    *off_min;     // per leaf, 3 floats: component-wise min of its offsets (-inf if non-finite)

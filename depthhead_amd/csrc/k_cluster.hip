@@ -208,7 +208,7 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
         auto leaf_alone = [&](const uint32_t l, const uint4 d) {
             const uint32_t v = lh[l] * a.f.leaf_v[l];                        // times the leaf voted x valtoadd
             for (uint32_t q = d.z; q < d.z + d.w; ++q) {
-                const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                      // prediction.rs:635
+                const uint32_t b = a.f.rot_bin[q], vm = v * (b >> 24);                                            // prediction.rs:635
                 uint32_t dx = (b & 255u) - (uint32_t)org[0];
                 uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
                 uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
@@ -264,16 +264,16 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
                     }
                 }
                 for (;;) {
-                    uint32_t b[LI], mu[LI];
+                    uint32_t b[LI];
 #pragma unroll
-                    for (uint32_t u = 0; u < LI; ++u) { const uint32_t qq = q[u] < q1[u] ? q[u] : 0u; b[u] = a.f.rot_bin[qq]; mu[u] = a.f.rot_mult[qq]; }
+                    for (uint32_t u = 0; u < LI; ++u) b[u] = a.f.rot_bin[q[u] < q1[u] ? q[u] : 0u];
                     bool more = false;
 #pragma unroll
                     for (uint32_t u = 0; u < LI; ++u) {
                         uint32_t dx = (b[u] & 255u) - (uint32_t)org[0];
                         uint32_t dy = ((b[u] >> 8) & 255u) - (uint32_t)org[1];
                         uint32_t dz = ((b[u] >> 16) & 255u) - (uint32_t)org[2];
-                        if (q[u] < q1[u] && dx < EDGE && dy < EDGE && dz < EDGE) atomicAdd(&region[(dx * EDGE + dy) * EDGE + dz], vm[u] * mu[u]);   // prediction.rs:635
+                        if (q[u] < q1[u] && dx < EDGE && dy < EDGE && dz < EDGE) atomicAdd(&region[(dx * EDGE + dy) * EDGE + dz], vm[u] * (b[u] >> 24));   // prediction.rs:635
                         q[u] += LL;
                         more = more || q[u] < q1[u];
                     }
@@ -304,7 +304,7 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
                 if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], EDGE)) continue;
                 const uint32_t v = vv[j];
                 for (uint32_t q = r[j].z; q < r[j].z + (r[j].w & 0xffffu); ++q) {
-                    const uint32_t b = a.f.rot_bin[q], vm = v * a.f.rot_mult[q];                                   // prediction.rs:635
+                    const uint32_t b = a.f.rot_bin[q], vm = v * (b >> 24);                                         // prediction.rs:635
                     uint32_t dx = (b & 255u) - (uint32_t)org[0];
                     uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
                     uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(256) k_votes_dump(VotesDumpArgs a) {
                 uint32_t k = atomicAdd(a.count, 1u);
                 if (k < a.cap) {
                     a.out[k * 4 + 0] = (int32_t)(b & 255u); a.out[k * 4 + 1] = (int32_t)((b >> 8) & 255u);
-                    a.out[k * 4 + 2] = (int32_t)((b >> 16) & 255u); a.out[k * 4 + 3] = (int32_t)(v * a.f.rot_mult[r]);
+                    a.out[k * 4 + 2] = (int32_t)((b >> 16) & 255u); a.out[k * 4 + 3] = (int32_t)(v * (b >> 24));
                 }
             }
         }

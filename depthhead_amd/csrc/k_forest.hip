@@ -104,6 +104,19 @@ __global__ void __launch_bounds__(256) k_leaf_prepare(DevForest f) {
         if (j == n_rough) { f.rot_rough[rb + j] = (uint16_t)rough; f.rough_mult[rb + j] = 0; n_rough++; }
         f.rough_mult[rb + j]++;
     }
+    // The multiplicity moves into the free top byte of its bin (one load per cell in the mean shift's gathers); a bin with more
+    // than 255 votes becomes several entries.  Expanded in place from the back: the entries never outnumber the leaf's votes.
+    {
+        uint32_t e = 0;
+        for (uint32_t j = 0; j < n_fine; ++j) e += ((uint32_t)f.rot_mult[rb + j] + 254u) / 255u;
+        uint32_t pos = e;
+        for (uint32_t j = n_fine; j-- > 0;) {
+            const uint32_t bin = f.rot_bin[rb + j] & 0xFFFFFFu;
+            uint32_t m = f.rot_mult[rb + j];
+            while (m) { const uint32_t part = m > 255u ? 255u : m; f.rot_bin[rb + --pos] = bin | (part << 24); m -= part; }
+        }
+        n_fine = e;
+    }
     f.leaf_v[L] = v;
     f.leaf_flags[L] = (uint8_t)flags;
     for (int k = 0; k < 3; ++k) { f.off_min[L * 3 + k] = omin[k]; f.off_max[L * 3 + k] = omax[k]; }

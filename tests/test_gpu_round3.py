@@ -336,3 +336,49 @@ def test_windows_that_travel_inside_and_beyond_the_blocks_of_k_region(hp_mod, or
     finally:
         for k in env:
             os.environ.pop(k, None)
+
+
+# ------------------------------------------------------------------ rotation bins with more than 255 votes
+@pytest.mark.parametrize("leaf_hist", [True, False])
+def test_leaves_with_hundreds_of_equal_rotations(hp_mod, oracle, leaf_hist):
+    """k_leaf_prepare keeps a leaf's DISTINCT rotation bins with the number of votes in the bin's top byte: a bin that collects
+    more than 255 of the leaf's votes becomes several entries (255 + 255 + ...).  Three single-split trees whose leaves hold
+    700 / 256 / 255 / 300 + 300 / 1 / 511 rotations, most of them equal: the full rotation accumulator (every cell and value)
+    and both mean shifts against the oracle, through the leaf histogram and through the rotation records."""
+    from depthhead_amd.forest import Forest, NODE_DTYPE
+    from test_gpu_parity import _check_frames
+    nodes = np.zeros(3, dtype=NODE_DTYPE)
+    nodes[0] = ((4, 4, 28, 28), (40, 40, 64, 64), 0.0, ~0, ~1)
+    nodes[1] = ((10, 30, 34, 54), (44, 6, 68, 30), 10.0, ~2, ~3)
+    nodes[2] = ((0, 0, 24, 24), (56, 56, 80, 80), -5.0, ~4, ~5)
+    roots = np.array([0, 1, 2], dtype=np.int32)
+    prob = np.array([1.0, 0.9, 0.95, 1.0, 0.8, 1.0])
+    n = [700, 256, 255, 600, 1, 511]
+    begin = np.concatenate([[0], np.cumsum(n)]).astype(np.uint32)
+    rs = np.random.RandomState(11)
+    centre = rs.uniform(-20, 20, (6, 3))
+    rotations = np.repeat(centre, n, axis=0)
+    rotations[int(begin[3]) + 300:int(begin[4])] += 3.0              # leaf 3: two bins of 300 votes each
+    rotations[int(begin[0]):int(begin[0]) + 40] += rs.uniform(-6, 6, (40, 3))   # leaf 0: 660 equal votes and 40 scattered ones
+    offsets = (np.repeat(rs.uniform(-30, 30, (6, 3)), n, axis=0) + rs.uniform(-1, 1, (int(begin[-1]), 3))).astype(np.float32)
+    forest = Forest(roots, nodes, prob, begin, begin.copy(), offsets, rotations)
+    base = synth.biwi_like(640, 480, 777)
+    ys, xs = np.nonzero(base)
+    cy, cx = int(ys.mean()), int(xs.mean())
+    frames = np.stack([base[cy - 60:cy + 60, cx - 70:cx + 70], base[cy - 40:cy + 80, cx - 90:cx + 50]]).copy()
+    model = synth.ModelParams(stepwidth=4)
+    K = synth.default_intrinsic(140, 120)
+    env = {} if leaf_hist else {"DH_NO_LEAF_HIST": "1"}
+    os.environ.update(env)
+    try:
+        _check_frames(hp_mod, oracle, forest, model, frames, K, full=True)
+        for extra in ({"DH_REGION_MIN_HITS": "1"},):                  # ... and through k_region's blocks
+            os.environ.update(extra)
+            try:
+                _check_frames(hp_mod, oracle, forest, model, frames, K, full=True)
+            finally:
+                for k in extra:
+                    os.environ.pop(k, None)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
