@@ -34,6 +34,6 @@ for tile, top in combos:
                 hp.predict_batch_device(fr.data_ptr(), 1, W, H, intr, out.data_ptr(), stream=st.cuda_stream)
                 for k, v in hp.timing().items():
                     acc[k] = acc.get(k, 0.0) + v / 40
-        print(f"{W}x{H} s{stride} DH_TILE={tile} DH_TOP_LEVELS={top} -> tile {geo['px']}x{geo['py']} top {geo['top_levels']} traverse {acc['traverse_ms']*1e3:6.1f} emit {acc['emit_ms']*1e3:5.1f} total {acc['total_ms']*1e3:6.1f} us same_pose {pose == ref}")
+        print(f"{W}x{H} s{stride} DH_TILE={tile} DH_TOP_LEVELS={top} -> tile {geo['px']}x{geo['py']} top {geo['top_levels']} boxsum {acc['boxsum_ms']*1e3:5.1f} traverse {acc['traverse_ms']*1e3:6.1f} emit {acc['emit_ms']*1e3:5.1f} total {acc['total_ms']*1e3:6.1f} us same_pose {pose == ref}")
     finally:
         for k in env: os.environ.pop(k, None)
