@@ -16,7 +16,10 @@
 // when the 20^3 window would leave it (it moves by a few cells per step after the first).
 // The weighted sums run over the non-zero window cells in the reference's x -> y -> z order
 // (meanshift.rs:344-381) as a strictly sequential f32 chain on 4 lanes (num.x, num.y, num.z, den);
-// everything off that chain (cell compaction, kernel weight, products) is done by all threads.
+// everything off that chain is parallel: per-row occupancy masks of the region (built once per region) name the
+// non-zero cells, a prefix sum over the window's 400 rows places them, the rows' threads write the products.
+// What the kernel costs is the rotation workgroup's chain of DEPENDENT round trips and barriers (guess -> list of the
+// leaves that voted -> their cells -> three or four sums), not work: see DESIGN.md section 4 and profiles/r03_cluster_phases.txt.
 #define CL_THREADS 1024
 #define CL_WAVES (CL_THREADS / WAVE)
 #define CL_PROD_CAP 384         // products staged per pass (x4 floats = 6 KB)
