@@ -34,8 +34,31 @@ def dfs_order(f):
     return np.array(out)
 
 
+def blocked_order(f, levels=3):
+    """Subtrees of `levels` levels (7 nodes = 112 bytes of walk table, one 128-byte line) stored together, blocks breadth-first."""
+    cz, co = f.nodes["child_zero"], f.nodes["child_one"]
+    out = []
+    for r in f.roots:
+        if r < 0:
+            continue
+        blocks = [int(r)]
+        while blocks:
+            nxt = []
+            for top in blocks:
+                level = [top]
+                for d in range(levels):
+                    out.extend(level)
+                    kids = [int(c) for n in level for c in (cz[n], co[n]) if c >= 0]
+                    if d == levels - 1:
+                        nxt.extend(kids)
+                    level = kids
+            blocks = nxt
+    return np.array(out)
+
+
 W, H, NF = 640, 480, 256
-base = synth.fit_forest(10, 15, synth.FOREST_SEED_BASE + 2)
+kind = sys.argv[1] if len(sys.argv) > 1 else "fitted"
+base = synth.fit_forest(10, 15, synth.FOREST_SEED_BASE + 2) if kind == "fitted" else synth.synth_forest(10, 15, synth.FOREST_SEED_BASE + 2)
 model = synth.ModelParams(stepwidth=4)
 dev = torch.device("cuda:0")
 frames = torch.from_numpy(np.concatenate([synth.biwi_batch(64, W, H)] * 4).view(np.int16)).to(dev)
@@ -43,7 +66,8 @@ intr = IntrinsicMatrix(synth.default_intrinsic(W, H))
 out = torch.zeros(NF * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
 st = torch.cuda.current_stream(dev)
 rs = np.random.RandomState(1)
-variants = {"breadth-first (as built)": base, "depth-first": renumber(base, dfs_order(base)), "random": renumber(base, rs.permutation(len(base.nodes)))}
+variants = {"breadth-first (as built)": base, "depth-first": renumber(base, dfs_order(base)), "random": renumber(base, rs.permutation(len(base.nodes))),
+            "blocks of 3 levels": renumber(base, blocked_order(base, 3)), "blocks of 2 levels": renumber(base, blocked_order(base, 2))}
 ref = None
 for rep in range(2):
     for name, f in variants.items():
