@@ -337,6 +337,7 @@ static int predictor_build(dh_predictor *p, const dh_forest *f, const dh_params 
     STEP(dev_alloc(p, &d.rot_rough, p->n_rot, true));
     STEP(dev_alloc(p, &d.rot_mult, p->n_rot, true));
     STEP(dev_alloc(p, &d.rough_mult, p->n_rot, true));
+    STEP(dev_alloc(p, &d.rough_cell, p->n_rot, true));
     STEP(dev_alloc(p, &d.off_min, (size_t)p->n_leaves * 3, true));
     STEP(dev_alloc(p, &d.off_max, (size_t)p->n_leaves * 3, true));
     STEP(dev_alloc(p, &d.rbin_box, p->n_leaves, true));

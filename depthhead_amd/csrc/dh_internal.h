@@ -52,8 +52,9 @@ struct DevForest {
     // leaf's slice [rot_begin, rot_begin + n) of these arrays holds its DISTINCT cells + multiplicities
     uint32_t *rot_bin;     // distinct fine bins r1 | r2<<8 | r3<<16 | votes<<24 (:605-627; a bin with more than 255 votes: several entries)
     uint16_t *rot_mult;    // (k_leaf_prepare's scratch: votes per distinct fine bin before they move into rot_bin's top byte)
-    uint16_t *rot_rough;   // distinct indices into the 20^3 guess grid   (:630-636)
-    uint16_t *rough_mult;  // votes per distinct guess-grid cell
+    uint16_t *rot_rough;   // (k_leaf_prepare's scratch) distinct indices into the 20^3 guess grid   (:630-636)
+    uint16_t *rough_mult;  // (scratch) votes per distinct guess-grid cell
+    uint32_t *rough_cell;  // the two as one word per distinct guess-grid cell: index | votes << 16 (one load per cell in k_vote)
     float    *off_min;     // per leaf, 3 floats: component-wise min of its offsets (-inf if non-finite)
     float    *off_max;     // per leaf, 3 floats                                     (+inf if non-finite)
     uint32_t *rbin_box;    // per leaf: component-wise minimum of its rotation bins, r1 | r2<<8 | r3<<16

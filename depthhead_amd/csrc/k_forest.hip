@@ -117,6 +117,7 @@ __global__ void __launch_bounds__(256) k_leaf_prepare(DevForest f) {
         }
         n_fine = e;
     }
+    for (uint32_t j = 0; j < n_rough; ++j) f.rough_cell[rb + j] = (uint32_t)f.rot_rough[rb + j] | ((uint32_t)f.rough_mult[rb + j] << 16);
     f.leaf_v[L] = v;
     f.leaf_flags[L] = (uint8_t)flags;
     for (int k = 0; k < 3; ++k) { f.off_min[L * 3 + k] = omin[k]; f.off_max[L * 3 + k] = omax[k]; }

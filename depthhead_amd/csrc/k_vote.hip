@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         const uint4 rr = a.leaf_hits ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4 *)(hr + i);   // rotation cells: only without the leaf histogram
         const uint32_t v = (uint32_t)b1.z, fc = (uint32_t)b1.w;
         if ((fc & LF_ROT) && !a.leaf_hits)
-            for (uint32_t r = rr.z + sub; r < rr.z + (rr.w >> 16); r += VOTE_SUB) atomicAdd(&rot[a.f.rot_rough[r]], v * a.f.rough_mult[r]);   // :636
+            for (uint32_t r = rr.z + sub; r < rr.z + (rr.w >> 16); r += VOTE_SUB) { const uint32_t c = a.f.rough_cell[r]; atomicAdd(&rot[c & 0xffffu], v * (c >> 16)); }   // :636
         // the pinhole form of the projection is taken by whole waves (a wave with one hit whose operands are not finite and
         // small takes the general expression for all of its hits: a uniform branch, not a per-lane select of both results)
         const bool pin_lane = PIN && (fc & LF_FIN) && fabsf(rec.x) < 1.0e30f && fabsf(rec.y) < 1.0e30f && fabsf(rec.z) < 1.0e30f;
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
             const uint4 t1 = tp[1], t2 = tp[2], t3 = tp[3];
             if (!(t1.w & LF_ROT)) continue;
             const uint32_t cv = c * t1.z;                      // count x valtoadd
-            for (uint32_t r = t2.w; r < t2.w + (t3.x >> 16); ++r) atomicAdd(&rot[a.f.rot_rough[r]], cv * a.f.rough_mult[r]);   // :636
+            for (uint32_t r = t2.w; r < t2.w + (t3.x >> 16); ++r) { const uint32_t c = a.f.rough_cell[r]; atomicAdd(&rot[c & 0xffffu], cv * (c >> 16)); }   // :636
         }
     }
     __syncthreads();
