@@ -542,6 +542,7 @@ def other_configs(args, dev, stream):
     Ks = synth.default_intrinsic(320, 240)
     one("c5_320x240_s1_graph", fitted, 1, small, small_np, 64, 320, 240, Ks, graph=True)   # configs[4] on one GPU, hipGraph replay
     one("c5_320x240_s1_single_frame_graph", fitted, 1, small, small_np, 1, 320, 240, Ks, graph=True, steps=50, check=1)
+    one("c5_320x240_s1_graph_synth_forest", rnd, 1, small, small_np, 64, 320, 240, Ks, graph=True, check=2)   # ... with BASELINE.md section 4's random stress forest
     c3 = synth.synth_forest(50, 20, synth.FOREST_SEED_BASE + 3)
     one("c3_50x20_s2_32f", c3, 2, fr256, base256, 32, W, H, K, steps=3, check=2)    # configs[2]: 50 trees, depth 20, stride 2, batch 32
     in_flight("c3_50x20_s2_32f_4_in_flight", c3, 2, fr256, 32, W, H)
