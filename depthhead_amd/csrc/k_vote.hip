@@ -96,7 +96,9 @@ __device__ __forceinline__ void vote_positions(const VoteArgs &a, uint32_t *pos,
 // five are x * 0 or z * 1.  For finite operands they are exact no-ops -- a + (+-0) = a, and the sign of a zero sum only
 // matters for r2, restored by adding +0 -- so four products and three sums give bit-identical r.  Hits whose window centre or
 // leaf offsets are not finite and small (LF_FIN) take the general expression (there 0 * inf = NaN must propagate).
-template <bool TAB, bool PIN>
+// LH: the batch has a leaf histogram (VoteArgs::leaf_hits): rotation cells come from the leaves that voted, not from the hit
+// records (an instance of its own: the other path's registers would cost the 80-VGPR instance a wave per SIMD).
+template <bool TAB, bool PIN, bool LH>
 __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
     __shared__ uint32_t pos[DH_POSGRID];
     __shared__ uint32_t rot[DH_GRID3];
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
     const uint32_t slices = gridDim.x;
     const uint32_t per = (n + slices - 1) / slices;
     const uint32_t h0 = min(n, blockIdx.x * per), h1 = min(n, h0 + per);
-    if (n == 0 || (h0 >= h1 && !a.leaf_hits)) return;       // with the leaf histogram every slice also owns a share of the leaves
+    if (n == 0 || (h0 >= h1 && !LH)) return;       // with the leaf histogram every slice also owns a share of the leaves
     for (int i = tid; i < DH_POSGRID; i += VOTE_THREADS) pos[i] = 0;
     for (int i = tid; i < DH_GRID3; i += VOTE_THREADS) rot[i] = 0;
     if (TAB) {
@@ -134,9 +136,9 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         const int4 b1 = b1_n;
         const uint32_t i_next = i + VOTE_THREADS / VOTE_SUB;
         if (i_next < h1) { rec_n = *(const float4 *)(hits + i_next); b1_n = ((const int4 *)(box + i_next))[1]; }
-        const uint4 rr = a.leaf_hits ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4 *)(hr + i);   // rotation cells: only without the leaf histogram
+        const uint4 rr = LH ? make_uint4(0u, 0u, 0u, 0u) : *(const uint4 *)(hr + i);   // rotation cells: only without the leaf histogram
         const uint32_t v = (uint32_t)b1.z, fc = (uint32_t)b1.w;
-        if ((fc & LF_ROT) && !a.leaf_hits)
+        if (!LH && (fc & LF_ROT))
             for (uint32_t r = rr.z + sub; r < rr.z + (rr.w >> 16); r += VOTE_SUB) { const uint32_t c = a.f.rough_cell[r]; atomicAdd(&rot[c & 0xffffu], v * (c >> 16)); }   // :636
         // the pinhole form of the projection is taken by whole waves (a wave with one hit whose operands are not finite and
         // small takes the general expression for all of its hits: a uniform branch, not a per-lane select of both results)
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) k_vote(VoteArgs a) {
         }
     }
     if (KNOB_STOP(a.stop == 2)) return;
-    if (a.leaf_hits) {
+    if (LH) {
         // Rotation votes depend only on the leaf (prediction.rs:601-636): with the per-frame leaf histogram the
         // 20^3 guess grid is the sum over the leaves that voted of count x v x (their distinct cells); u32
         // wrap-around makes that the same residue as count separate adds.  The slices share the leaves.
@@ -181,12 +183,18 @@ hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s) {
     b.cell_fast = a.cell_fast && a.w % DH_GRID == 0 && a.h % DH_GRID == 0 && a.w > 0 && a.h > 0;
     b.sx = (float)DH_GRID / (float)a.w; b.sy = (float)DH_GRID / (float)a.h;
     b.kxs = a.k[0] * b.sx; b.cxs = a.k[2] * b.sx; b.kys = a.k[4] * b.sy; b.cys = a.k[5] * b.sy;   // (one f32 rounding each: see vote_positions)
+#define VOTE_LAUNCH(TAB_, PIN_)                                                                       \
+    do {                                                                                             \
+        if (b.leaf_hits) hipLaunchKernelGGL((k_vote<TAB_, PIN_, true>), grid, block, 0, s, b);       \
+        else hipLaunchKernelGGL((k_vote<TAB_, PIN_, false>), grid, block, 0, s, b);                  \
+    } while (0)
     if (a.w <= VOTE_TAB && a.h <= VOTE_TAB) {
-        if (pin) hipLaunchKernelGGL((k_vote<true, true>), grid, block, 0, s, b);
-        else hipLaunchKernelGGL((k_vote<true, false>), grid, block, 0, s, b);
+        if (pin) VOTE_LAUNCH(true, true);
+        else VOTE_LAUNCH(true, false);
     } else {
-        if (pin) hipLaunchKernelGGL((k_vote<false, true>), grid, block, 0, s, b);
-        else hipLaunchKernelGGL((k_vote<false, false>), grid, block, 0, s, b);
+        if (pin) VOTE_LAUNCH(false, true);
+        else VOTE_LAUNCH(false, false);
     }
+#undef VOTE_LAUNCH
     return hipGetLastError();
 }
