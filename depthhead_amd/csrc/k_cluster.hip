@@ -305,13 +305,18 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
                 if (!range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], EDGE)) continue;
                 if (!range_hits_span((int32_t)((bl >> 8) & 255u), (int32_t)((bh >> 8) & 255u), org[1], EDGE)) continue;
                 if (!range_hits_span((int32_t)((bl >> 16) & 255u), (int32_t)((bh >> 16) & 255u), org[2], EDGE)) continue;
-                const uint32_t v = vv[j];
-                for (uint32_t q = r[j].z; q < r[j].z + (r[j].w & 0xffffu); ++q) {
-                    const uint32_t b = a.f.rot_bin[q], vm = v * (b >> 24);                                         // prediction.rs:635
-                    uint32_t dx = (b & 255u) - (uint32_t)org[0];
-                    uint32_t dy = ((b >> 8) & 255u) - (uint32_t)org[1];
-                    uint32_t dz = ((b >> 16) & 255u) - (uint32_t)org[2];
-                    if (dx < EDGE && dy < EDGE && dz < EDGE) atomicAdd(&region[(dx * EDGE + dy) * EDGE + dz], vm);
+                const uint32_t v = vv[j], q1 = r[j].z + (r[j].w & 0xffffu);
+                for (uint32_t q0 = r[j].z; q0 < q1; q0 += 4u) {             // four of the record's cells in flight (one load each)
+                    uint32_t b[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) b[u] = a.f.rot_bin[min(q0 + u, q1 - 1u)];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        uint32_t dx = (b[u] & 255u) - (uint32_t)org[0];
+                        uint32_t dy = ((b[u] >> 8) & 255u) - (uint32_t)org[1];
+                        uint32_t dz = ((b[u] >> 16) & 255u) - (uint32_t)org[2];
+                        if (q0 + u < q1 && dx < EDGE && dy < EDGE && dz < EDGE) atomicAdd(&region[(dx * EDGE + dy) * EDGE + dz], v * (b[u] >> 24));   // prediction.rs:635
+                    }
                 }
             }
         }
