@@ -20,10 +20,7 @@
 // non-zero cells, a prefix sum over the window's 400 rows places them, the rows' threads write the products.
 // What the kernel costs is the rotation workgroup's chain of DEPENDENT round trips and barriers (guess -> list of the
 // leaves that voted -> their cells -> three or four sums), not work: see DESIGN.md section 4 and profiles/r03_cluster_phases.txt.
-#ifndef CL_THREADS
 #define CL_THREADS 1024
-#endif
-#define CL_PER 2048 / CL_THREADS          // records a thread keeps in flight in the record gathers (2 at 1024 threads)
 #define CL_WAVES (CL_THREADS / WAVE)
 #define CL_PROD_CAP 384         // products staged per pass (x4 floats = 6 KB)
 #define CL_LIST (CL_PROD_CAP * 4) // survivors of the region gathers' bounding-box tests listed in `prod` (1536)
@@ -169,15 +166,15 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
         uint32_t *list = (uint32_t *)prod;
         if (tid == 0) s_total = 0;
         __syncthreads();
-        for (uint32_t i0 = h0; i0 < h1; i0 += CL_THREADS * (CL_PER)) {  // (uniform trip count: the ballots need every lane)
-            int4 b0[CL_PER], b1[CL_PER];
+        for (uint32_t i0 = h0; i0 < h1; i0 += CL_THREADS * 2) {        // (uniform trip count: the ballots need every lane)
+            int4 b0[2], b1[2];
 #pragma unroll
-            for (int j = 0; j < CL_PER; ++j) {                              // two records' boxes in flight (64-VGPR budget)
+            for (int j = 0; j < 2; ++j) {                                   // two records' boxes in flight (64-VGPR budget)
                 const uint32_t i = min(i0 + j * CL_THREADS + tid, h1 - 1);
                 b0[j] = ((const int4 *)(box + i))[0]; b1[j] = ((const int4 *)(box + i))[1];
             }
 #pragma unroll
-            for (int j = 0; j < CL_PER; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 const uint32_t i = i0 + j * CL_THREADS + tid, fc = (uint32_t)b1[j].w;
                 const bool keep = i < h1 && (fc & LF_OFF) && range_hits_span(b0[j].x, b0[j].w, org[0], EDGE) &&
                                   range_hits_span(b0[j].y, b1[j].x, org[1], EDGE) && range_hits_span(b0[j].z, b1[j].y, org[2], EDGE);
@@ -221,7 +218,7 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
                 if (dx < EDGE && dy < EDGE && dz < EDGE) atomicAdd(&region[(dx * EDGE + dy) * EDGE + dz], vm);
             }
         };
-        constexpr uint32_t LR = 4096 / CL_THREADS, LL = 8, LI = 4096 / CL_THREADS;                             // leaves per thread and scan round; lanes per listed leaf; items in flight
+        constexpr uint32_t LR = 4, LL = 8, LI = 4;                             // leaves per thread and scan round; lanes per listed leaf; items in flight
         for (uint32_t c0 = l0; c0 < l1; c0 += LR * CL_THREADS) {
             if (tid == 0) s_total = 0;
             __syncthreads();
@@ -292,17 +289,17 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
         // (forests without a leaf histogram: every thread takes its own records' rotation cells.  The two-step survivor list
         // of the position gather was tried here in round 3 and lost: 0.130 vs 0.119 ms on the 35 k-leaf forest -- a record has
         // at most a few dozen distinct cells, and the loads of a thread's loop are independent.)
-        for (uint32_t i0 = h0; i0 < h1; i0 += CL_THREADS * (CL_PER)) {
-            uint4 r[CL_PER];
-            uint32_t vv[CL_PER];
+        for (uint32_t i0 = h0; i0 < h1; i0 += CL_THREADS * 2) {
+            uint4 r[2];
+            uint32_t vv[2];
 #pragma unroll
-            for (int j = 0; j < CL_PER; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 uint32_t i = i0 + j * CL_THREADS + tid;
                 r[j].x = 0xFFFFFFFFu;
                 if (i < h1) { r[j] = *(const uint4 *)(hr + i); vv[j] = box[i].v; }
             }
 #pragma unroll
-            for (int j = 0; j < CL_PER; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 const uint32_t bl = r[j].x, bh = r[j].y;
                 if (bl == 0xFFFFFFFFu) continue;
                 if (!range_hits_span((int32_t)(bl & 255u), (int32_t)(bh & 255u), org[0], EDGE)) continue;
@@ -340,7 +337,7 @@ __device__ __forceinline__ void cl_gather(const ClusterArgs &a, const int which,
 // SUP: the batch has blocks of both accumulators in global memory (k_region; a.pre_region != NULL); a separate instance so that
 // the code of batches without them keeps its registers.
 template <bool SUP>
-__global__ void __launch_bounds__(CL_THREADS, CL_THREADS / 128) k_cluster(ClusterArgs a) {
+__global__ void __launch_bounds__(CL_THREADS, 8) k_cluster(ClusterArgs a) {
     __shared__ uint32_t region[RG3];
     __shared__ __attribute__((aligned(16))) float prod[CL_PROD_CAP * 4];
     __shared__ uint32_t cnt[CL_WAVES];
@@ -555,7 +552,7 @@ hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s) {
 // frames (up to 18 cells in 20 iterations) and the rotation window up to 4 cells, and every 26^3 region a window outgrew used to
 // cost a scan of all the frame's records by one workgroup (0.55 ms of that step for one rotation rebuild).
 template <int WHICH>
-__global__ void __launch_bounds__(CL_THREADS, CL_THREADS / 128) k_region(ClusterArgs a) {
+__global__ void __launch_bounds__(CL_THREADS, 8) k_region(ClusterArgs a) {
     extern __shared__ uint32_t block[];                             // WHICH == 1: [RRG3]
     __shared__ __attribute__((aligned(16))) float prod[CL_PROD_CAP * 4];
     __shared__ unsigned long long red64[CL_WAVES];
@@ -569,7 +566,7 @@ __global__ void __launch_bounds__(CL_THREADS, CL_THREADS / 128) k_region(Cluster
     if (n_hits < a.pre_min_hits) return;                            // few records: k_cluster gathers this frame's regions itself
     // this workgroup's share: hit records in whole rounds of the gather loops, leaves in whole list chunks
     const uint32_t S = (uint32_t)a.pre_slices;
-    const uint32_t hper = ((n_hits + S - 1) / S + 2048 - 1) / 2048 * 2048;
+    const uint32_t hper = ((n_hits + S - 1) / S + 2 * CL_THREADS - 1) / (2 * CL_THREADS) * (2 * CL_THREADS);
     const uint32_t h0 = min(n_hits, (uint32_t)slice * hper), h1 = min(n_hits, h0 + hper);
     const uint32_t lper = ((a.f.n_leaves + S - 1) / S + CL_LIST - 1) / CL_LIST * CL_LIST;
     const uint32_t l0 = min(a.f.n_leaves, (uint32_t)slice * lper), l1 = min(a.f.n_leaves, l0 + lper);
