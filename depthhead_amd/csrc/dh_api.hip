@@ -423,8 +423,9 @@ static int predictor_sigma_(const dh_predictor *p, float *out) {
     return DH_OK;
 }
 
-static int choose_tile(const dh_predictor *p, Geom &g) {
+static int choose_tile(const dh_predictor *p, Geom &g, int cap) {
     TileQuery q;
+    q.one_pass = cap == 1 && p->knobs.tile_x == 0;     // (a workspace for ONE frame: see dh_choose_tile_)
     q.params = p->params; q.f_rw = p->f_rw; q.f_rh = p->f_rh; q.n_trees = p->n_trees; q.absorb_ok = p->absorb_ok; q.top_levels = p->top_levels;
     q.lds_budget_kb = p->knobs.lds_budget_kb; q.tile_x = p->knobs.tile_x; q.tile_y = p->knobs.tile_y; q.box_band = p->knobs.box_band;
     return dh_choose_tile_(q, g);
@@ -448,8 +449,8 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
         // uniform-rectangle fast path: one rectangle size (<= 96 x 96, so a k_boxsum wave yields
         // >= 160 columns), rectangle sums fit i32
         g.uniform = p->f_uniform && (long)p->f_rw * p->f_rh <= 32768 && p->f_rw <= kBoxMaxRect && p->f_rh <= kBoxMaxRect && !p->knobs.force_general;
-        rc = choose_tile(p, g);
-        if (rc > 0) { g.uniform = false; rc = choose_tile(p, g); }   // no tile fits the uniform layout
+        rc = choose_tile(p, g, cap);
+        if (rc > 0) { g.uniform = false; rc = choose_tile(p, g, cap); }   // no tile fits the uniform layout
         if (rc) return rc;
     }
     size_t hits_cap = std::max<size_t>((size_t)g.npatch * p->n_trees, 1);
