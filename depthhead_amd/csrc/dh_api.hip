@@ -585,7 +585,9 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     // (with the taps on, every tile position keeps its workgroup: those of empty tiles write the taps' "background")
     // (also for a single frame: skipping the list's launch was measured in round 3 and k_traverse alone got 10 us slower than
     // the 5 us the list costs -- profiles/r03_single_frame.md)
-    const bool use_list = p->tile_list && g.npatch > 0 && !leaf_out && !flags_out && !p->debug;
+    // (the list moves the empty tiles' workgroups behind the flagged ones; a batch whose tiles all fit the chip's 512 workgroup
+    // slots at once gains nothing from that and saves the dispatch: 3 us of a single frame's 96)
+    const bool use_list = p->tile_list && g.npatch > 0 && !leaf_out && !flags_out && !p->debug && (long)n * g.tiles_x * g.tiles_y > 512;
     uint32_t *tl_list = use_list ? p->tile_list + (size_t)chunk * 8 * (p->tile_list_stride + 1) : nullptr;
     uint32_t *tl_count = use_list ? tl_list + 8 * p->tile_list_stride : nullptr;
     if (use_list) { Range r(profile, "dh:tile_list"); HIP_TRY(dh_launch_tile_list(tile_flags, n, g.tiles_x * g.tiles_y, tl_list, tl_count, (uint32_t)p->tile_list_stride, s)); }

@@ -166,7 +166,7 @@ hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s) {
     // 8-byte row loads need w % 4 == 0 and 8-byte aligned frames; rw % 4 == 0 gives a 16-byte LDS read-back;
     // a.ring: the host sized the bands for the LDS-ring instance (rh - 1 packed rows per wave)
     const bool al = (a.w & 3) == 0 && (((size_t)a.frames) & 7) == 0, rw4 = (a.rw & 3) == 0;
-    const dim3 grid(8, a.blocks_per_frame, fb), block(BOXW_THREADS);
+    const dim3 grid((unsigned)std::min(8, a.n_frames), a.blocks_per_frame, fb), block(BOXW_THREADS);
     const size_t ring_bytes = a.ring ? (size_t)BOXW_WAVES * (a.rh - 1) * WAVE * sizeof(uint2) : 0;
     if (a.ring) {
         if (al && rw4) hipLaunchKernelGGL((k_boxsum<true, true, true>), grid, block, ring_bytes, s, a);

@@ -765,6 +765,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, TRAV_THREADS / 128) k_traverse(T
 // stream capture, so dh_predictor_create calls it, with the device current).  Predictors are created concurrently by
 // independent host threads (the header allows it): the per-device flags are atomics and a second caller that finds the
 // flag clear simply sets the same value again.
+#include <algorithm>
 #include <atomic>
 hipError_t dh_kernels_init(int device) {
     static std::atomic<unsigned long long> done[4];                 // one bit per device id < 256
@@ -784,7 +785,7 @@ hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream
     const int tiles = a.tiles_x * a.tiles_y, fb = (a.n_frames + 7) / 8;
     if (tiles == 0 || fb == 0) return hipSuccess;
     if (tiles > 65535 || fb > 65535) return hipErrorInvalidConfiguration;
-    const dim3 grid(8, tiles, fb);
+    const dim3 grid((unsigned)std::min(8, a.n_frames), tiles, fb);      // (fewer than 8 frames: no workgroups for the frames that are not there)
     if (a.uniform && a.nodes_a) hipLaunchKernelGGL((k_traverse<true, true>), grid, dim3(TRAV_THREADS), lds_bytes, s, a);
     else if (a.uniform) hipLaunchKernelGGL((k_traverse<true, false>), grid, dim3(TRAV_THREADS), lds_bytes, s, a);
     else if (a.nodes_g) hipLaunchKernelGGL((k_traverse<false, true>), grid, dim3(TRAV_THREADS), lds_bytes, s, a);
