@@ -149,6 +149,8 @@ struct dh_predictor {
     int leaf_ls = 2;                 // log2 of its entry size
     uint32_t *leaf_hits = nullptr;   // [cap][n_leaves] rotation-vote histogram (inside `counters`), only for forests of <= DH_LEAF_HIST_MAX leaves
     size_t zero_words = 0;           // words of `counters` zeroed before every batch
+    uint32_t *gen = nullptr;         // [DH_MAX_CHUNKS] tile-flag tags, one per kernel sequence in flight (BoxArgs::gen)
+    size_t zero_lo = 0, zero_hi = 0; // the tile flags' words inside `counters`: [zero_lo, zero_hi)
     uint32_t hits_cap = 0;
     uint32_t *pre_region = nullptr;  // [pre_cap][2][64^3] the cells of both accumulators around the initial guesses, gathered by k_region (small batches with many hit records)
     int pre_cap = 0;
@@ -252,6 +254,7 @@ static int predictor_destroy_(dh_predictor *p) {
     if (p->kern_r2) (void)hipFree(p->kern_r2);
     if (p->blur_kern) (void)hipFree(p->blur_kern);
     if (p->zeros) (void)hipFree(p->zeros);
+    if (p->gen) (void)hipFree(p->gen);
     for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     for (auto &e : p->ev_join) if (e) (void)hipEventDestroy(e);
@@ -346,6 +349,7 @@ static int predictor_build(dh_predictor *p, const dh_forest *f, const dh_params 
     STEP(dev_alloc(p, &d.rot_dir, p->n_leaves, true));
     STEP(dev_alloc(p, &p->kern_r2, DH_KERN_R2));
     STEP(dev_alloc(p, &p->zeros, 32));
+    STEP(dev_alloc(p, &p->gen, DH_MAX_CHUNKS));
     { uint4 *nu = nullptr; STEP(dev_alloc(p, &nu, p->n_nodes, true)); p->nodes_u = nu; }
     if (p->n_nodes > 0 && (size_t)p->n_nodes + p->n_leaves + 2 * DH_AMB_CAP < ((size_t)1 << 27) && !p->knobs.no_absorb) {   // (byte offsets into the table stay below 2^31)
         STEP(dev_alloc(p, &p->amb_flag, 1, true));
@@ -365,6 +369,7 @@ static int predictor_build(dh_predictor *p, const dh_forest *f, const dh_params 
         if (rc == DH_OK && e != hipSuccess) rc = fail(DH_EHIP, "%s: %s", what, hipGetErrorString(e));
     };
     if (rc == DH_OK) hipstep(hipMemset(p->zeros, 0, 64), "hipMemset");
+    if (rc == DH_OK) { const uint32_t ones[DH_MAX_CHUNKS] = {1, 1, 1, 1, 1, 1, 1, 1}; hipstep(hipMemcpy(p->gen, ones, sizeof ones, hipMemcpyHostToDevice), "hipMemcpy(gen)"); }
     if (rc == DH_OK) hipstep(dh_kernels_init(device), "hipFuncSetAttribute");
     if (rc == DH_OK) hipstep(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking), "hipStreamCreate");
     if (rc == DH_OK) hipstep(dh_launch_leaf_prepare(d, p->own_stream), "k_leaf_prepare launch");
@@ -497,6 +502,10 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     STEP(dev_alloc(p, &p->counters, counter_words + (leaf_hist ? (size_t)cap * p->n_leaves : 0) + 4));   // (+4: the zero-fill kernel rounds up to 16 bytes)
     if (rc == DH_OK) p->leaf_hits = leaf_hist ? p->counters + counter_words : nullptr;
     p->zero_words = counter_words + (leaf_hist ? (size_t)cap * p->n_leaves : 0);
+    // (zeroed once here: the tile flags carry tags and get no fill of their own when k_boxsum clears the other counters)
+    if (rc == DH_OK && (hipMemsetAsync(p->counters, 0, (p->zero_words + 4) * sizeof(uint32_t), p->own_stream) != hipSuccess ||
+                        hipStreamSynchronize(p->own_stream) != hipSuccess)) rc = fail(DH_EHIP, "zero-fill of the counters");
+    p->zero_lo = (size_t)cap * (1 + DH_POSGRID + DH_GRID3); p->zero_hi = p->zero_lo + (size_t)cap * g.flag_words;
     STEP(dev_alloc(p, &p->ws_poses, cap));
     STEP(dev_alloc(p, &p->ws_midp, (size_t)cap * 3));
     STEP(dev_alloc(p, &p->ws_rot, (size_t)cap * 3));
@@ -534,8 +543,9 @@ static int predictor_reserve_(dh_predictor *p, int n, int w, int h) {
 static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n, int w, int h, const float K[9],
                          const float kinv[9], const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask,
                          dh_pose *out, hipStream_t s, bool profile, int32_t *leaf_out = nullptr, uint8_t *flags_out = nullptr,
-                         bool traverse_only = false, int chunk = 0) {
+                         bool traverse_only = false, int chunk = 0, bool zero_fold = false) {
     const Geom &g = p->geom;
+    uint32_t *gen = p->gen + chunk;      // this kernel sequence's tile-flag tag
     uint32_t *hit_count = p->counters + f0;
     uint32_t *pos_grid = p->counters + p->cap_frames + (size_t)f0 * DH_POSGRID;
     uint32_t *rot_grid = p->counters + p->cap_frames + (size_t)p->cap_frames * DH_POSGRID + (size_t)f0 * DH_GRID3;
@@ -551,7 +561,8 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     if (g.npatch > 0 && g.uniform) {
         BoxArgs ba{};
         ba.frames = fr; ba.zeros = p->zeros; ba.n_frames = n; ba.w = w; ba.h = h; ba.rw = p->f_rw; ba.rh = p->f_rh;
-        ba.tile_flags = tile_flags; ba.tiles_x = g.tiles_x; ba.tiles_y = g.tiles_y;
+        ba.tile_flags = tile_flags; ba.tiles_x = g.tiles_x; ba.tiles_y = g.tiles_y; ba.gen = gen;
+        if (zero_fold) { ba.zero_ptr = p->counters; ba.zero_lo = (uint32_t)p->zero_lo; ba.zero_hi = (uint32_t)p->zero_hi; ba.zero_end = (uint32_t)p->zero_words; }
         ba.tpx = g.px * (int)p->params.stepwidth; ba.tpy = g.py * (int)p->params.stepwidth;
         ba.tbw = (g.px - 1) * (int)p->params.stepwidth + (int)p->params.subimage_width - p->f_rw + 1;
         ba.tbh = (g.py - 1) * (int)p->params.stepwidth + (int)p->params.subimage_height - p->f_rh + 1;
@@ -574,7 +585,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     }
     if (g.npatch > 0 && !g.uniform) {
         PixFlagArgs fa{};
-        fa.frames = fr; fa.n_frames = n; fa.w = w; fa.h = h; fa.tile_flags = tile_flags;
+        fa.frames = fr; fa.n_frames = n; fa.w = w; fa.h = h; fa.tile_flags = tile_flags; fa.gen = gen;
         fa.tiles_x = g.tiles_x; fa.tiles_y = g.tiles_y;
         fa.tpx = g.px * (int)p->params.stepwidth; fa.tpy = g.py * (int)p->params.stepwidth;
         fa.tfw = (g.px - 1) * (int)p->params.stepwidth + (int)p->params.subimage_width;
@@ -583,14 +594,12 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
     }
     // product mode: the flagged tiles as compact lists, so that the workgroups of empty tiles sit at the end of k_traverse's grid
     // (with the taps on, every tile position keeps its workgroup: those of empty tiles write the taps' "background")
-    // (also for a single frame: skipping the list's launch was measured in round 3 and k_traverse alone got 10 us slower than
-    // the 5 us the list costs -- profiles/r03_single_frame.md)
     // (the list moves the empty tiles' workgroups behind the flagged ones; a batch whose tiles all fit the chip's 512 workgroup
     // slots at once gains nothing from that and saves the dispatch: 3 us of a single frame's 96)
     const bool use_list = p->tile_list && g.npatch > 0 && !leaf_out && !flags_out && !p->debug && (long)n * g.tiles_x * g.tiles_y > 512;
     uint32_t *tl_list = use_list ? p->tile_list + (size_t)chunk * 8 * (p->tile_list_stride + 1) : nullptr;
     uint32_t *tl_count = use_list ? tl_list + 8 * p->tile_list_stride : nullptr;
-    if (use_list) { Range r(profile, "dh:tile_list"); HIP_TRY(dh_launch_tile_list(tile_flags, n, g.tiles_x * g.tiles_y, tl_list, tl_count, (uint32_t)p->tile_list_stride, s)); }
+    if (use_list) { Range r(profile, "dh:tile_list"); HIP_TRY(dh_launch_tile_list(tile_flags, gen, n, g.tiles_x * g.tiles_y, tl_list, tl_count, (uint32_t)p->tile_list_stride, s)); }
     if (profile) HIP_TRY(hipEventRecord(p->ev[4], s));
     if (g.npatch > 0) {
         TraverseArgs ta{};
@@ -601,7 +610,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         ta.uniform = g.uniform ? 1 : 0; ta.rw = p->f_rw; ta.rh = p->f_rh; ta.area = (uint32_t)(p->f_rw * p->f_rh);
         ta.nodes_u = p->nodes_u; ta.nodes_a = p->absorb_ok ? p->nodes_a : nullptr; ta.walk_lb = (p->n_nodes + p->n_amb) << 4; ta.amb_list = p->amb_list; ta.top_tab = p->top_tab; ta.top_levels = g.top_levels; ta.nodes_g = p->knobs.no_general_int ? nullptr : p->nodes_g;
         ta.box = box; ta.box_plane = g.box_plane; ta.box_rows = g.box_rows;
-        ta.tile_flags = tile_flags;
+        ta.tile_flags = tile_flags; ta.gen = gen;
 #ifdef DH_PROFILING_KNOBS
         ta.stop_phase = p->knobs.trav_stop;
         static unsigned long long *stamps = nullptr;
@@ -637,6 +646,7 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
             ea.hits = p->hits + hoff; ea.hit_box = p->hit_box + hoff; ea.hit_rot = p->hit_rot + hoff;
             ea.hit_count = hit_count; ea.hits_cap = p->hits_cap;
             ea.leaf_hits = p->leaf_hits ? p->leaf_hits + (size_t)f0 * p->n_leaves : nullptr;
+            ea.gen = gen;
             ea.dbg_flags = ta.dbg_flags;
 #ifdef DH_PROFILING_KNOBS
             ea.stop = p->knobs.emit_stop;
@@ -728,9 +738,6 @@ static int predict_batch_device_(dh_predictor *p, const uint16_t *frames, int n,
     dh_mat3_inv_f32_(K, kinv);   // cached in a RefCell by the reference (types.rs:436-441)
     for (int f0 = 0; f0 < n; f0 += slice) {
         const int m = std::min(slice, n - f0);
-        // (inside a captured graph the zero-fill is a kernel node: see k_zero)
-        if (p->capturing) HIP_TRY(dh_launch_zero(p->counters, (p->zero_words * sizeof(uint32_t) + 15) & ~(size_t)15, s));
-        else HIP_TRY(hipMemsetAsync(p->counters, 0, p->zero_words * sizeof(uint32_t), s));
         const uint16_t *fr = frames + (size_t)f0 * w * h;
         const float *mg = midp_guess ? midp_guess + (size_t)f0 * 3 : nullptr;
         const double *rg = rot_guess ? rot_guess + (size_t)f0 * 3 : nullptr;
@@ -742,8 +749,17 @@ static int predict_batch_device_(dh_predictor *p, const uint16_t *frames, int n,
         int chunks = p->chunks > 0 ? p->chunks : (m >= 512 ? 2 : 1);
         if (p->profiling || p->debug || p->capturing || m < 2 * DH_MIN_CHUNK_FRAMES) chunks = 1;
         chunks = std::min(chunks, m / DH_MIN_CHUNK_FRAMES);
+        // The per-batch counters: one kernel sequence on the uniform path has them cleared by its first kernel (k_boxsum: every
+        // wave of its grid takes a share; the tile flags carry tags and need no fill) -- one dispatch less per batch, 4.7 us of a
+        // single frame's 95.  Forked sub-batches, the general path and frames smaller than the patch keep the fill.
+        const bool fold = chunks <= 1 && p->geom.uniform && p->geom.npatch > 0 && p->zero_words < 0xffffffffull && !p->knobs.no_zero_fold;
+        if (!fold) {
+            // (inside a captured graph the zero-fill is a kernel node: see k_zero)
+            if (p->capturing) HIP_TRY(dh_launch_zero(p->counters, (p->zero_words * sizeof(uint32_t) + 15) & ~(size_t)15, s));
+            else HIP_TRY(hipMemsetAsync(p->counters, 0, p->zero_words * sizeof(uint32_t), s));
+        }
         if (chunks <= 1) {
-            rc = enqueue_range(p, fr, 0, m, w, h, K, kinv, mg, rg, gm, out + f0, s, p->profiling);
+            rc = enqueue_range(p, fr, 0, m, w, h, K, kinv, mg, rg, gm, out + f0, s, p->profiling, nullptr, nullptr, false, 0, fold);
             if (rc) return rc;
         } else {
             HIP_TRY(hipEventRecord(p->ev_fork, s));

@@ -193,6 +193,7 @@ Knobs dh_read_knobs_() {
     k.no_absorb = getenv("DH_NO_ABSORB") != nullptr;
     k.vote_exact = getenv("DH_VOTE_EXACT") != nullptr;
     k.no_tile_list = getenv("DH_NO_TILE_LIST") != nullptr;
+    k.no_zero_fold = getenv("DH_NO_ZERO_FOLD") != nullptr;
     if (const char *e = getenv("DH_TOP_LEVELS")) k.top_levels = std::max(0, std::min(8, atoi(e)));
     k.stage_chunk = std::max(1, geti("DH_STAGE_CHUNK", 64));
     k.host_threads = std::max(1, std::min(64, geti("DH_HOST_THREADS", (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())))));

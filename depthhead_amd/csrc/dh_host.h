@@ -86,6 +86,7 @@ struct Knobs {
     bool no_region = false;           // DH_NO_REGION: k_cluster always gathers its first region itself
     int region_min_hits = 0;          // DH_REGION_MIN_HITS: hit records in a frame from which k_region pre-gathers (0 = automatic)
     int top_levels = -1;              // DH_TOP_LEVELS: tree levels walked from the LDS copy of the tree tops (-1 = auto, 0 = none)
+    bool no_zero_fold = false;        // DH_NO_ZERO_FOLD: the per-batch counters get a fill dispatch of their own instead of being cleared by k_boxsum
     bool no_tile_list = false;        // DH_NO_TILE_LIST: k_traverse launches a workgroup per tile position, empty ones included
     bool vote_exact = false;          // DH_VOTE_EXACT: k_vote takes the two IEEE divisions for every vote
     bool no_absorb = false;           // DH_NO_ABSORB: uniform path walks the guarded node table

@@ -106,7 +106,8 @@ struct TraverseArgs {
     const uint32_t *tile_list;       // nullable: [8][tile_list_stride] the flagged (frame group << 16 | tile) pairs per x = frame mod 8 (k_tile_list)
     const uint32_t *tile_list_count; // [8]
     uint32_t tile_list_stride;
-    const uint8_t *tile_flags; // [n_frames][tiles] 1 = the tile's region holds a non-zero box sum (k_boxsum) / its footprint a non-zero pixel (k_pixflags)
+    const uint32_t *gen;       // the batch's tile-flag tag (BoxArgs::gen)
+    const uint8_t *tile_flags; // [n_frames][tiles] == *gen: the tile's region holds a non-zero box sum (k_boxsum) / its footprint a non-zero pixel (k_pixflags)
     const void *nodes_u;    // NodeU[n_nodes], built by k_nodes_compact for this region layout
     const void *nodes_a;    // uniform path: NodeU[n_nodes + n_amb + 1] walk table (children as byte offsets; walk_absorb, k_nodes_compact), or NULL
     uint32_t walk_lb;        // with nodes_a: byte offset of the entry behind its nodes ((n_nodes + n_amb) << 4); leaf l is walk_lb + 16 l
@@ -147,6 +148,7 @@ struct EmitArgs {
     uint32_t *hit_count;    // [n_frames]
     uint32_t  hits_cap;     // records per frame
     uint32_t *leaf_hits;    // nullable [n_frames][n_leaves]: how often each leaf cast rotation votes (zeroed per batch)
+    uint32_t *gen;          // nullable: the tile-flag tag of this kernel sequence, moved on here (every reader of the batch's flags has run)
     uint8_t  *dbg_flags;    // nullable [n][npatch]: bit 1 set for windows that pass the gate
     int stop;               // profiling knob (env DH_EMIT_STOP): 1 / 2 = return after the window lookup / after the gate
 };
@@ -161,7 +163,11 @@ struct BoxArgs {
     uint32_t *out;
     int plane, rows, lg;    // a row is (1 << lg) planes of `plane` words (multiple of 4): column x sits in plane x mod m at x / m; rows = h - rh + 1
     int ow, oh;             // rectangle origins one wave produces: ow columns (multiple of 4, <= 256 - rw) x oh rows
-    uint8_t *tile_flags;    // [n_frames][tiles_x * tiles_y] k_traverse tiles with a non-zero sum in their region; zeroed per batch by the host
+    uint8_t *tile_flags;    // [n_frames][tiles_x * tiles_y] k_traverse tiles with a non-zero sum in their region: set to the batch's TAG (*gen)
+    const uint32_t *gen;    // the batch's tile-flag tag, 1 .. 255 (k_emit moves it on): a flag holding any other value is clear -- or a stale,
+                            // harmless false positive (the flags are conservative) -- so the flags never need a fill
+    uint32_t *zero_ptr;     // nullable: the per-batch counters [0, zero_lo) and [zero_hi, zero_end) (words), zeroed by this kernel's waves
+    uint32_t zero_lo, zero_hi, zero_end;   // instead of by a fill of their own (the tile flags sit in [zero_lo, zero_hi))
     int tiles_x, tiles_y;   // k_traverse's tiling: tile (tx, ty) reads columns [tx * tpx, tx * tpx + tbw), rows [ty * tpy, ty * tpy + tbh)
     int tpx, tpy, tbw, tbh;
     int parts, bands;       // waves across / down a frame
@@ -179,7 +185,8 @@ struct BoxArgs {
 struct PixFlagArgs {
     const uint16_t *frames;
     int n_frames, w, h;
-    uint8_t *tile_flags;    // [n_frames][tiles_x * tiles_y], zeroed per batch by the host
+    uint8_t *tile_flags;    // [n_frames][tiles_x * tiles_y], set to the batch's tag
+    const uint32_t *gen;    // see BoxArgs
     int tiles_x, tiles_y;   // tile (tx, ty) covers pixel columns [tx * tpx, tx * tpx + tfw), rows [ty * tpy, ty * tpy + tfh)
     int tpx, tpy, tfw, tfh;
 };
@@ -284,7 +291,7 @@ hipError_t dh_launch_nodes_compact(const DevForest &f, int ss, int swz_log2, int
                                    uint32_t *amb_list, uint32_t n_amb, hipStream_t s);
 #define DH_AMB_CAP 4096      // ambiguous nodes the walk table can hold (more: the guarded node table is walked)
 hipError_t dh_launch_traverse(const TraverseArgs &a, size_t lds_bytes, hipStream_t s);
-hipError_t dh_launch_tile_list(const uint8_t *flags, int n_frames, int tiles, uint32_t *list, uint32_t *count, uint32_t stride, hipStream_t s);
+hipError_t dh_launch_tile_list(const uint8_t *flags, const uint32_t *gen, int n_frames, int tiles, uint32_t *list, uint32_t *count, uint32_t stride, hipStream_t s);
 hipError_t dh_launch_emit(const EmitArgs &a, hipStream_t s);
 hipError_t dh_launch_vote(const VoteArgs &a, hipStream_t s);
 hipError_t dh_launch_cluster(const ClusterArgs &a, hipStream_t s);

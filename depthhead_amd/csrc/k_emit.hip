@@ -16,6 +16,9 @@
 template <int EB, int LS>      // LS: log2 of the window list's leaf entry size (dh_device.h: load_leaf)
 __global__ void __launch_bounds__(EMIT_THREADS) k_emit(EmitArgs a) {
     const int frame = blockIdx.y, lane = threadIdx.x & (WAVE - 1);
+    // every reader of this batch's tile flags (k_tile_list, k_traverse) has run: the next batch of this kernel sequence takes
+    // the next tag, 1 .. 255 (BoxArgs::gen)
+    if (a.gen && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.gen = *a.gen % 255u + 1u;
     const int pp = a.px * a.py;
     // Thread i of the frame takes the i-th active window in tile order: every wave scans the tiles'
     // counts itself (64 tiles per step, one load per lane) and finds its tile with a binary search

@@ -59,6 +59,7 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
     const int o2 = ((x + 2) & mm) * a.plane + ((x + 2) >> a.lg), o3 = ((x + 3) & mm) * a.plane + ((x + 3) >> a.lg);
     uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, acc = 0;
     uint8_t *flags = a.tile_flags + (size_t)frame * a.tiles_x * a.tiles_y;
+    const uint8_t tag = (uint8_t)*a.gen;             // this batch's tile-flag tag
     const float r_tpx = 1.0f / (float)a.tpx, r_tpy = 1.0f / (float)a.tpy;
     uint2 e[RIF], l[RIF], en[RIF], ln[RIF];
     int rs = 0;                          // ring slot of step t: t mod (rh - 1)
@@ -113,7 +114,7 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
             v0 -= l[k].x & 0xffffu; v1 -= l[k].x >> 16; v2 -= l[k].y & 0xffffu; v3 -= l[k].y >> 16;
             // Which k_traverse tiles have a non-zero rectangle sum in their region?  Every 32 output rows
             // (and at the end of the band) each lane that saw a non-zero sum marks the tiles whose regions
-            // contain its columns and those rows (plain stores of 1: the flags are zeroed per batch).
+            // contain its columns and those rows (plain stores of the batch's tag).
             const int yo = Y0 + t - warm;
             if ((yo & 31) == 31 || yo == y_end - 1) {
                 if (bm) {
@@ -128,7 +129,7 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
                     const int tx1 = min(div_small(x + 3, a.tpx, r_tpx), a.tiles_x - 1), tx0 = max(x - a.tbw < 0 ? 0 : div_small(x - a.tbw, a.tpx, r_tpx) + 1, 0);
                     const int ty1 = min(div_small(yo, a.tpy, r_tpy), a.tiles_y - 1), ty0 = max(y_lo - a.tbh + 1 <= 0 ? 0 : div_small(y_lo - a.tbh, a.tpy, r_tpy) + 1, 0);
                     for (int ty = ty0; ty <= ty1; ++ty)
-                        for (int tx = tx0; tx <= tx1; ++tx) flags[ty * a.tiles_x + tx] = 1;
+                        for (int tx = tx0; tx <= tx1; ++tx) flags[ty * a.tiles_x + tx] = tag;
                 }
                 acc = 0;
             }
@@ -143,6 +144,14 @@ __global__ void __launch_bounds__(BOXW_THREADS) k_boxsum(BoxArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t pex_s[BOXW_WAVES][BOX_SPAN + BOX_MAXR + 8];
     extern __shared__ __attribute__((aligned(16))) uint32_t box_dyn[];       // RING: [BOXW_WAVES][rh - 1][64] packed rows
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    if (a.zero_ptr) {
+        // the batch's other counters (hit counters, guess grids, window counts, leaf histogram): this is the first kernel of the
+        // batch and none of them is touched before the next one, so every wave of the grid clears a share -- no fill dispatch
+        const size_t nw = (size_t)gridDim.x * gridDim.y * gridDim.z * BOXW_THREADS;
+        const size_t gi = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * BOXW_THREADS + threadIdx.x;
+        for (size_t i = gi; i < a.zero_lo; i += nw) a.zero_ptr[i] = 0u;
+        for (size_t i = (size_t)a.zero_hi + gi; i < a.zero_end; i += nw) a.zero_ptr[i] = 0u;
+    }
     const int frame = (int)blockIdx.z * 8 + (int)blockIdx.x;     // grid (8, blocks per frame, frames / 8): same frame -> XCD mapping as k_traverse
     const int unit = (int)blockIdx.y * BOXW_WAVES + wv;
     if (frame >= a.n_frames || unit >= a.bands * a.parts) return;      // waves are independent: no barriers below
@@ -186,13 +195,14 @@ hipError_t dh_launch_boxsum(const BoxArgs &a, hipStream_t s) {
 // General (mixed-rectangle) path: which k_traverse tiles have a non-zero pixel under their footprint?
 // One workgroup scans a band of 32 image rows of one frame (8-byte loads, 4 columns per lane); a lane
 // that saw a non-zero pixel marks the tiles whose footprints contain its columns and the band's rows
-// (plain stores of 1; the flags are zeroed per batch).  Conservative by construction.
+// (plain stores of the batch's tag, BoxArgs::gen).  Conservative by construction.
 __global__ void __launch_bounds__(256) k_pixflags(PixFlagArgs a) {
     const int frame = (int)blockIdx.z * 8 + (int)blockIdx.x;
     if (frame >= a.n_frames) return;
     const int y0 = (int)blockIdx.y * 32, y1 = min(y0 + 32, a.h);
     const uint16_t *img = a.frames + (size_t)frame * a.w * a.h;
     uint8_t *flags = a.tile_flags + (size_t)frame * a.tiles_x * a.tiles_y;
+    const uint8_t tag = (uint8_t)*a.gen;
     const float r_tpx = 1.0f / (float)a.tpx, r_tpy = 1.0f / (float)a.tpy;
     const bool al = (a.w & 3) == 0 && (((size_t)a.frames) & 7) == 0;
     for (int x = 4 * (int)threadIdx.x; x < a.w; x += 4 * 256) {
@@ -208,7 +218,7 @@ __global__ void __launch_bounds__(256) k_pixflags(PixFlagArgs a) {
         const int tx1 = min(div_small(min(x + 3, a.w - 1), a.tpx, r_tpx), a.tiles_x - 1), tx0 = x - a.tfw < 0 ? 0 : div_small(x - a.tfw, a.tpx, r_tpx) + 1;
         const int ty1 = min(div_small(y1 - 1, a.tpy, r_tpy), a.tiles_y - 1), ty0 = y0 - a.tfh < 0 ? 0 : div_small(y0 - a.tfh, a.tpy, r_tpy) + 1;
         for (int ty = ty0; ty <= ty1; ++ty)
-            for (int tx = tx0; tx <= tx1; ++tx) flags[ty * a.tiles_x + tx] = 1;
+            for (int tx = tx0; tx <= tx1; ++tx) flags[ty * a.tiles_x + tx] = tag;
     }
 }
 
@@ -226,8 +236,9 @@ hipError_t dh_launch_pixflags(const PixFlagArgs &a, hipStream_t s) {
 // k-th entry; the workgroups beyond a list's end -- the flagged-empty tiles, four in seven on the bench frames -- then sit at the
 // END of the grid, where they leave at once instead of each holding a workgroup slot (79 KB of LDS) for the 1-2 us it takes a
 // workgroup to start, read its flag and go, in the middle of the real work.
-__global__ void __launch_bounds__(1024) k_tile_list(const uint8_t *flags, int n_frames, int tiles, uint32_t *list, uint32_t *count, uint32_t stride) {
+__global__ void __launch_bounds__(1024) k_tile_list(const uint8_t *flags, const uint32_t *gen, int n_frames, int tiles, uint32_t *list, uint32_t *count, uint32_t stride) {
     __shared__ uint32_t wsum[16];
+    const uint8_t tag = (uint8_t)*gen;
     const int x = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
     const uint32_t fb = (uint32_t)(n_frames + 7) / 8, total = fb * (uint32_t)tiles;
     uint32_t base = 0;
@@ -235,7 +246,7 @@ __global__ void __launch_bounds__(1024) k_tile_list(const uint8_t *flags, int n_
         const uint32_t e = e0 + (uint32_t)tid;
         const uint32_t z = e / (uint32_t)tiles, t = e - z * (uint32_t)tiles;
         const uint32_t frame = z * 8 + (uint32_t)x;
-        const bool on = e < total && frame < (uint32_t)n_frames && flags[(size_t)frame * tiles + t] != 0;
+        const bool on = e < total && frame < (uint32_t)n_frames && flags[(size_t)frame * tiles + t] == tag;
         const unsigned long long bal = __ballot(on);
         if (lane == 0) wsum[wv] = (uint32_t)__popcll(bal);
         __syncthreads();
@@ -248,9 +259,9 @@ __global__ void __launch_bounds__(1024) k_tile_list(const uint8_t *flags, int n_
     if (tid == 0) count[x] = base;
 }
 
-hipError_t dh_launch_tile_list(const uint8_t *flags, int n_frames, int tiles, uint32_t *list, uint32_t *count, uint32_t stride, hipStream_t s) {
+hipError_t dh_launch_tile_list(const uint8_t *flags, const uint32_t *gen, int n_frames, int tiles, uint32_t *list, uint32_t *count, uint32_t stride, hipStream_t s) {
     if (n_frames == 0 || tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tile_list, dim3(8), dim3(1024), 0, s, flags, n_frames, tiles, list, count, stride);
+    hipLaunchKernelGGL(k_tile_list, dim3(8), dim3(1024), 0, s, flags, gen, n_frames, tiles, list, count, stride);
     return hipGetLastError();
 }
 

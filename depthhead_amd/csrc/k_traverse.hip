@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(TRAV_THREADS, TRAV_THREADS / 128) k_traverse(T
     // k_boxsum (uniform path) / k_pixflags (general path) flagged the tiles whose region holds a non-zero
     // rectangle sum / whose footprint holds a non-zero pixel; any other tile has only background windows
     // (prediction.rs:567-576) and leaves before building anything
-    bool nonzero = a.tile_list != nullptr || a.tile_flags[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] != 0;
+    bool nonzero = a.tile_list != nullptr || a.tile_flags[(size_t)frame * (a.tiles_x * a.tiles_y) + tile] == (uint8_t)*a.gen;
     if (tid < 8) misc[tid] = 0;
     if (!UNI) __syncthreads();        // (the uniform path's copy ends with a barrier before misc is used)
     if (UNI && nonzero) {

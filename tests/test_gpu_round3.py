@@ -407,3 +407,46 @@ def test_single_frame_workspace_takes_one_pass_tiles(hp_mod, oracle, w, h, strid
     ref = oracle.predict_batch(forest, model, frames, K)
     assert _poses_equal(one, ref[:1]) and _poses_equal(three, ref)
     _check_frames(hp_mod, oracle, forest, model, frames[:1], K, full=False)
+
+
+# ------------------------------------------------------------------ tile-flag tags across their wrap-around
+def test_tile_flag_tags_wrap_around(hp_mod, oracle):
+    """The tile flags carry a per-batch tag (1 .. 255, moved on by k_emit) instead of being zeroed per batch, and k_boxsum clears
+    the batch's other counters itself: a stale tag can only be a false positive (a tile walked for nothing).  280 batches through
+    ONE predictor -- past the wrap -- alternating frames whose occupied tiles differ (a subject left, right, none at all), every
+    pose against the oracle's; the same with the fill dispatch (DH_NO_ZERO_FOLD) and through a replayed hipGraph."""
+    torch = pytest.importorskip("torch")
+    from depthhead_amd._lib import POSE_DTYPE
+    forest = synth.fit_forest(6, 10, synth.FOREST_SEED_BASE + 9, n_frames=12, subset=1500)
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 320, 240
+    K = synth.default_intrinsic(w, h)
+    base = synth.biwi_batch(3, w, h, first=40)
+    frames = [base[0], np.roll(base[1], 90, axis=1), np.zeros((h, w), dtype=np.uint16), np.roll(base[2], -80, axis=1)]
+    ref = [oracle.predict_batch(forest, model, f[None], K)[0] for f in frames]
+    intr = hp_mod.IntrinsicMatrix(K)
+    for env in ({}, {"DH_NO_ZERO_FOLD": "1"}):
+        os.environ.update(env)
+        try:
+            with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+                for i in range(280):
+                    k = (i * 7 + i // 5) % 4
+                    got = hp.predict_batch(frames[k][None].copy(), intr)
+                    assert np.array_equal(got["mid_point"][0], ref[k]["mid_point"]) and np.array_equal(got["rotation"][0], ref[k]["rotation"]), (i, k, env)
+        finally:
+            for kk in env:
+                os.environ.pop(kk, None)
+    dev = torch.device("cuda:0")
+    fr = torch.zeros((1, h, w), dtype=torch.int16, device=dev)
+    out = torch.zeros(POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        hp.reserve(1, w, h)
+        hp.graph_capture(fr.data_ptr(), 1, w, h, intr, out.data_ptr())
+        for i in range(270):
+            k = (i * 3 + i // 7) % 4
+            fr.copy_(torch.from_numpy(frames[k][None].view(np.int16)))
+            hp.graph_launch(st.cuda_stream)
+            st.synchronize()
+            got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)
+            assert np.array_equal(got["mid_point"][0], ref[k]["mid_point"]) and np.array_equal(got["rotation"][0], ref[k]["rotation"]), ("graph", i, k)
