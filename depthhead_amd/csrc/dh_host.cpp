@@ -294,9 +294,10 @@ int dh_choose_tile_(const TileQuery &p, Geom &g) {
     long max_win = 1024;      // one thread per window position in the gate
 #endif
     // single-frame workspace (the live-camera loop of examples/live_prediction.rs:76-86): its tiles cannot fill the chip anyway, so
-    // smaller ones -- all walks of a tile in ONE lock-step pass of at most 4 per lane, the frame spread over more CUs -- cost
-    // nothing and shorten the frame's critical path (320 x 240 at stride 1: k_traverse 22 instead of 30 us, stride 2: 17 instead of 30)
-    if (p.one_pass && g.uniform && p.absorb_ok) max_win = std::max<long>(16, std::min<long>(max_win, 4096 / std::max<uint32_t>(p.n_trees, 1)));
+    // smaller ones -- all walks of a tile in ONE lock-step pass, wider than high (fewer region rows to copy), the frame spread over more CUs -- cost
+    // nothing and shorten the frame's critical path (one 320 x 240 frame at stride 1, host sync after each: 91.7 us with tiles of
+    // 24 x 17 windows, 90.0 with 20 x 20, 87.9 with 20 x 16, 88.5 with 16 x 12, 89.3 with 12 x 12; 32 x 32, the largest that fits: 95)
+    if (p.one_pass && g.uniform && p.absorb_ok) max_win = std::max<long>(16, std::min<long>(max_win, 3200 / std::max<uint32_t>(p.n_trees, 1)));
     long best = -1;
     for (int py = 1; py <= std::min(g.ny, 64); ++py)
         for (int px = 1; px <= std::min(g.nx, 64); ++px) {
@@ -309,6 +310,7 @@ int dh_choose_tile_(const TileQuery &p, Geom &g) {
             size_t lds = dh_traverse_lds_bytes(px, py, step, sw, sh, top_words, rw, rh);
             if (lds > budget && !(fx > 0 && lds <= 158 * 1024)) continue;
             long score = (long)px * py * 1000 - labs((long)px - py);
+            if (p.one_pass && g.uniform && p.absorb_ok) score = (long)px * py * 1000 + (px - py);
             if (score > best) { best = score; g.px = px; g.py = py; g.lds = lds; }
         }
     if (best < 0) {

@@ -125,7 +125,7 @@ struct TileQuery {
     uint32_t n_trees = 0;
     bool absorb_ok = false;          // the uniform path walks the walk table (tree tops in LDS)
     int top_levels = -1;             // forced number of LDS tree levels, or -1
-    bool one_pass = false;           // single-frame workspace: a tile holds at most 4096 / n_trees windows (its walks are ONE lock-step pass)
+    bool one_pass = false;           // single-frame workspace: a tile holds at most 3200 / n_trees windows (its walks are ONE lock-step pass), wider than high
     int lds_budget_kb = 0, tile_x = 0, tile_y = 0, box_band = 64;
 };
 // Tile of PX x PY window positions per workgroup for g.{w, h, nx, ny, uniform}: fills the rest of g.  Returns DH_OK,
