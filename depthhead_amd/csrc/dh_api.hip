@@ -151,6 +151,7 @@ struct dh_predictor {
     size_t zero_words = 0;           // words of `counters` zeroed before every batch
     uint32_t *gen = nullptr;         // [DH_MAX_CHUNKS] tile-flag tags, one per kernel sequence in flight (BoxArgs::gen)
     size_t zero_lo = 0, zero_hi = 0; // the tile flags' words inside `counters`: [zero_lo, zero_hi)
+    int blk_shift = 5;               // log2 height of k_boxsum's mask blocks in this workspace (BoxArgs::blk_shift)
     uint32_t hits_cap = 0;
     uint32_t *pre_region = nullptr;  // [pre_cap][2][64^3] the cells of both accumulators around the initial guesses, gathered by k_region (small batches with many hit records)
     int pre_cap = 0;
@@ -458,6 +459,7 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
         if (rc > 0) { g.uniform = false; rc = choose_tile(p, g, cap); }   // no tile fits the uniform layout
         if (rc) return rc;
     }
+    p->blk_shift = cap == 1 ? 3 : 5;
     size_t hits_cap = std::max<size_t>((size_t)g.npatch * p->n_trees, 1);
     if (hits_cap > 0xffffffffull) return fail(DH_ESIZE, "too many (patch, tree) pairs per frame");
     p->hits_cap = (uint32_t)hits_cap;
@@ -491,7 +493,7 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
         if (rc == DH_OK && hipMemsetAsync(p->box, 0, words * sizeof(uint32_t), p->own_stream) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box)");
         if (!p->knobs.box_dense) {
             // zeroed together with the images: "cell non-zero => mask bit set" holds from the start
-            const size_t mw = (size_t)cap * ((g.box_rows + 31) / 32) * g.box_parts;
+            const size_t mw = (size_t)cap * ((g.box_rows + 7) / 8) * g.box_parts;        // (sized for 8-row blocks: single-frame workspaces)
             STEP(dev_alloc(p, &p->box_mask, mw));
             if (rc == DH_OK && hipMemsetAsync(p->box_mask, 0, mw * sizeof(unsigned long long), p->own_stream) != hipSuccess) rc = fail(DH_EHIP, "hipMemset(box_mask)");
         }
@@ -573,12 +575,16 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         const bool ring_on = !p->knobs.box_no_ring;
         if (ring_on && p->f_rh >= 2 && p->f_rh - 1 <= 28) {      // 4 x 28 x 512 B + the prefix rows < 64 KB
             const long waves_max = 12L * 256;
-            int bands = (int)std::max(1L, std::min<long>(std::max(1, g.box_rows / 16), waves_max / std::max(1L, (long)n * g.box_parts)));
-            ba.oh = ((g.box_rows + bands - 1) / bands + 31) & ~31;               // whole 32-row blocks per band (BoxArgs::blk_mask)
+            // (a single-frame workspace: 8-row bands and mask blocks -- a wave's march of band + rh - 1 rows IS the kernel's
+            // duration there: 31 instead of 55 rows at rh = 24; one 320 x 240 frame 86 -> 79 us with 16-row bands, 76 with 8)
+            const int blk = 1 << p->blk_shift;
+            int bands = (int)std::max(1L, std::min<long>(std::max(1, (g.box_rows + blk - 1) / blk), waves_max / std::max(1L, (long)n * g.box_parts)));
+            ba.oh = ((g.box_rows + bands - 1) / bands + blk - 1) & ~(blk - 1);   // whole mask blocks per band (BoxArgs::blk_mask)
             ba.bands = (g.box_rows + ba.oh - 1) / ba.oh;
             ba.ring = 1;
         }
-        ba.mask_blocks = (g.box_rows + 31) / 32;
+        ba.blk_shift = p->blk_shift;
+        ba.mask_blocks = (g.box_rows + (1 << p->blk_shift) - 1) >> p->blk_shift;
         ba.blk_mask = p->box_mask ? p->box_mask + (size_t)f0 * ba.mask_blocks * g.box_parts : nullptr;
         ba.blocks_per_frame = (ba.parts * ba.bands + 3) / 4;
         { Range r(profile, "dh:boxsum"); HIP_TRY(dh_launch_boxsum(ba, s)); }

@@ -178,7 +178,8 @@ struct BoxArgs {
     // skips the store: the cells hold zero already (buffer and masks are zeroed together when the workspace is allocated, and every
     // fill keeps "cell non-zero => bit set").  Band heights are multiples of 32 rows so that one wave owns a block.  NULL: store everything.
     unsigned long long *blk_mask;
-    int mask_blocks;        // ceil(rows / 32)
+    int mask_blocks;        // ceil(rows / block height)
+    int blk_shift;          // log2 of the mask blocks' height: 5 (32 rows); 3 on single-frame workspaces, whose bands are 8 rows
 };
 
 // k_pixflags: tile flags of the general path (non-zero pixel under the tile's footprint).

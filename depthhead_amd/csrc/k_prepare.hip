@@ -65,8 +65,9 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
     int rs = 0;                          // ring slot of step t: t mod (rh - 1)
     // sparse stores (BoxArgs::blk_mask): the previous fill's non-zero mask of the 32-row block being emitted, and the next block's
     unsigned long long *bm = a.blk_mask ? a.blk_mask + ((size_t)frame * a.mask_blocks) * a.parts + part : nullptr;
-    unsigned long long pblk = bm ? bm[(size_t)(Y0 >> 5) * a.parts] : ~0ull;
-    unsigned long long pnext = bm && ((Y0 >> 5) + 1) < a.mask_blocks ? bm[(size_t)((Y0 >> 5) + 1) * a.parts] : ~0ull;
+    const int bsh = a.blk_shift, bmk = (1 << a.blk_shift) - 1;     // mask blocks of 32 rows (8 on single-frame workspaces)
+    unsigned long long pblk = bm ? bm[(size_t)(Y0 >> bsh) * a.parts] : ~0ull;
+    unsigned long long pnext = bm && ((Y0 >> bsh) + 1) < a.mask_blocks ? bm[(size_t)((Y0 >> bsh) + 1) * a.parts] : ~0ull;
 #pragma unroll
     for (int k = 0; k < RIF; ++k) {
         const int t = min(k, nsteps - 1);
@@ -112,20 +113,20 @@ __device__ __forceinline__ void boxsum_wave(const BoxArgs &a, int frame, const u
                 } else { orow[o0] = r.x - pe.x; orow[o1] = r.y - pe.y; orow[o2] = r.z - pe.z; orow[o3] = r.w - pe.w; }
             }
             v0 -= l[k].x & 0xffffu; v1 -= l[k].x >> 16; v2 -= l[k].y & 0xffffu; v3 -= l[k].y >> 16;
-            // Which k_traverse tiles have a non-zero rectangle sum in their region?  Every 32 output rows
+            // Which k_traverse tiles have a non-zero rectangle sum in their region?  Every mask block of output rows
             // (and at the end of the band) each lane that saw a non-zero sum marks the tiles whose regions
             // contain its columns and those rows (plain stores of the batch's tag).
             const int yo = Y0 + t - warm;
-            if ((yo & 31) == 31 || yo == y_end - 1) {
+            if ((yo & bmk) == bmk || yo == y_end - 1) {
                 if (bm) {
                     const unsigned long long nm = __ballot(acc != 0);
-                    if (lane == 0) bm[(size_t)(yo >> 5) * a.parts] = nm;
+                    if (lane == 0) bm[(size_t)(yo >> bsh) * a.parts] = nm;
                     pblk = pnext;
-                    pnext = ((yo >> 5) + 2) < a.mask_blocks ? bm[(size_t)((yo >> 5) + 2) * a.parts] : ~0ull;
+                    pnext = ((yo >> bsh) + 2) < a.mask_blocks ? bm[(size_t)((yo >> bsh) + 2) * a.parts] : ~0ull;
                 }
                 if (acc != 0) {
                     // tile tx covers columns [tx * tpx, tx * tpx + tbw): tx in [(x + 3 - tbw) / tpx + 1 .. x / tpx] clipped
-                    const int y_lo = max(yo & ~31, Y0);
+                    const int y_lo = max(yo & ~bmk, Y0);
                     const int tx1 = min(div_small(x + 3, a.tpx, r_tpx), a.tiles_x - 1), tx0 = max(x - a.tbw < 0 ? 0 : div_small(x - a.tbw, a.tpx, r_tpx) + 1, 0);
                     const int ty1 = min(div_small(yo, a.tpy, r_tpy), a.tiles_y - 1), ty0 = max(y_lo - a.tbh + 1 <= 0 ? 0 : div_small(y_lo - a.tbh, a.tpy, r_tpy) + 1, 0);
                     for (int ty = ty0; ty <= ty1; ++ty)
