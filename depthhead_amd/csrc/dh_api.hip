@@ -459,7 +459,12 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
         if (rc > 0) { g.uniform = false; rc = choose_tile(p, g, cap); }   // no tile fits the uniform layout
         if (rc) return rc;
     }
-    p->blk_shift = cap == 1 ? 3 : 5;
+    // k_boxsum's band / mask-block height: the shortest of 8, 16, 32 rows whose waves (12 per CU) still fit the chip at once for a
+    // workspace of this many frames -- with few frames a wave's march of band + rh - 1 rows IS that kernel's duration
+    p->blk_shift = 5;
+    if (g.uniform && g.box_rows > 0)
+        for (int sh = 3; sh < 5; ++sh)
+            if ((long)cap * g.box_parts * ((g.box_rows + (1 << sh) - 1) >> sh) <= 12L * 256) { p->blk_shift = sh; break; }
     size_t hits_cap = std::max<size_t>((size_t)g.npatch * p->n_trees, 1);
     if (hits_cap > 0xffffffffull) return fail(DH_ESIZE, "too many (patch, tree) pairs per frame");
     p->hits_cap = (uint32_t)hits_cap;
