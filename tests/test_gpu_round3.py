@@ -450,3 +450,37 @@ def test_tile_flag_tags_wrap_around(hp_mod, oracle):
             st.synchronize()
             got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)
             assert np.array_equal(got["mid_point"][0], ref[k]["mid_point"]) and np.array_equal(got["rotation"][0], ref[k]["rotation"]), ("graph", i, k)
+
+
+# ------------------------------------------------------------------ forked sub-batches: one tile-flag tag per kernel sequence
+@pytest.mark.parametrize("chunks", ["2", "4"])
+def test_forked_sub_batches_keep_their_own_tags(hp_mod, oracle, chunks):
+    """DH_CHUNKS forks a device batch into sub-batches on streams of their own (automatic from 512 frames): every kernel sequence in
+    flight has its own tile-flag tag and the batch keeps its fill dispatch.  96 device-resident frames, several calls through one
+    predictor (alternating with unforked calls, whose k_boxsum clears the counters itself), every pose against the oracle's."""
+    torch = pytest.importorskip("torch")
+    from depthhead_amd._lib import POSE_DTYPE
+    forest = synth.fit_forest(6, 10, synth.FOREST_SEED_BASE + 9, n_frames=12, subset=1500)
+    model = synth.ModelParams(stepwidth=4)
+    w, h, n = 320, 240, 96
+    K = synth.default_intrinsic(w, h)
+    base = synth.biwi_batch(24, w, h, first=70)
+    base[5] = 0
+    frames = base[np.arange(n) % 24]
+    ref = oracle.predict_batch(forest, model, base, K)[np.arange(n) % 24]
+    dev = torch.device("cuda:0")
+    fr = torch.from_numpy(frames.view(np.int16)).to(dev)
+    out = torch.zeros(n * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev)
+    intr = hp_mod.IntrinsicMatrix(K)
+    os.environ["DH_CHUNKS"] = chunks
+    try:
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            for rep in range(6):
+                m = n if rep % 2 == 0 else 24                     # 24 frames: below two chunks' minimum, one sequence
+                hp.predict_batch_device(fr.data_ptr(), m, w, h, intr, out.data_ptr(), stream=st.cuda_stream)
+                st.synchronize()
+                got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)[:m]
+                assert _poses_equal(got, ref[:m]), (chunks, rep)
+    finally:
+        os.environ.pop("DH_CHUNKS", None)
