@@ -42,7 +42,7 @@ class Timing(C.Structure):
 EXPORTS = [
     "dh_last_error", "dh_version", "dh_forest_create", "dh_forest_destroy", "dh_forest_info",
     "dh_predictor_create", "dh_predictor_destroy", "dh_predictor_update_sigma", "dh_predictor_sigma",
-    "dh_predict_batch", "dh_predict_batch_device", "dh_predict_batch_rle", "dh_biwi_decode_depth_device", "dh_host_alloc", "dh_host_free", "dh_predictor_reserve", "dh_patch_grid",
+    "dh_predict_batch", "dh_predict_batch_device", "dh_predict_batch_rle", "dh_biwi_decode_depth_device", "dh_host_alloc", "dh_host_free", "dh_predictor_reserve", "dh_predictor_set_forking", "dh_patch_grid",
     "dh_predict_mask", "dh_predict_mask_device", "dh_hough_image", "dh_hough_image_device", "dh_build_hough_image", "dh_build_hough_image_device",
     "dh_predict_from2dhough", "dh_predict_from2dhough_device",
     "dh_biwi_decode_depth", "dh_biwi_parse_cal", "dh_biwi_parse_pose",

@@ -541,6 +541,12 @@ static int reserve(dh_predictor *p, int n, int w, int h) {
     return DH_OK;
 }
 
+static int predictor_set_forking_(dh_predictor *p, int chunks) {
+    if (!p) return fail(DH_EINVAL, "NULL predictor");
+    if (chunks < 0 || chunks > DH_MAX_CHUNKS) return fail(DH_EINVAL, "dh_predictor_set_forking: chunks = %d, expected 0 .. %d", chunks, DH_MAX_CHUNKS);
+    p->chunks = chunks;
+    return DH_OK;
+}
 static int predictor_reserve_(dh_predictor *p, int n, int w, int h) {
     if (!p) return fail(DH_EINVAL, "NULL predictor");
     return reserve(p, n, w, h);
@@ -579,12 +585,16 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
         // 12 waves fit a CU; the bands are made as tall as keeps the whole launch resident at once
         const bool ring_on = !p->knobs.box_no_ring;
         if (ring_on && p->f_rh >= 2 && p->f_rh - 1 <= 28) {      // 4 x 28 x 512 B + the prefix rows < 64 KB
-            const long waves_max = 12L * 256;
             // (a single-frame workspace: 8-row bands and mask blocks -- a wave's march of band + rh - 1 rows IS the kernel's
             // duration there: 31 instead of 55 rows at rh = 24; one 320 x 240 frame 86 -> 79 us with 16-row bands, 76 with 8)
             const int blk = 1 << p->blk_shift;
-            int bands = (int)std::max(1L, std::min<long>(std::max(1, (g.box_rows + blk - 1) / blk), waves_max / std::max(1L, (long)n * g.box_parts)));
-            ba.oh = ((g.box_rows + bands - 1) / bands + blk - 1) & ~(blk - 1);   // whole mask blocks per band (BoxArgs::blk_mask)
+            int oh = 0;
+            int bands = dh_box_bands_(n, g.box_parts, g.box_rows, blk, p->f_rh, 3 * 256, &oh);
+            if (p->knobs.box_bands > 0) {                     // DH_BOX_BANDS: experiments
+                bands = std::min(p->knobs.box_bands, std::max(1, (g.box_rows + blk - 1) / blk));
+                oh = ((g.box_rows + bands - 1) / bands + blk - 1) & ~(blk - 1);
+            }
+            ba.oh = oh;                                       // whole mask blocks per band (BoxArgs::blk_mask)
             ba.bands = (g.box_rows + ba.oh - 1) / ba.oh;
             ba.ring = 1;
         }
@@ -1472,6 +1482,7 @@ DH_API(predictor_create, (const dh_forest *f, const dh_params *prm, int device, 
 DH_API(predictor_update_sigma, (dh_predictor *p, float val), (p, val))
 DH_API(predictor_sigma, (const dh_predictor *p, float *out), (p, out))
 DH_API(predictor_reserve, (dh_predictor *p, int n, int w, int h), (p, n, w, h))
+DH_API(predictor_set_forking, (dh_predictor *p, int chunks), (p, chunks))
 DH_API(predict_batch_device, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out, void *stream_), (p, frames, n, w, h, K, midp_guess, rot_guess, guess_mask, out, stream_))
 DH_API(predict_batch, (dh_predictor *p, const uint16_t *frames, int n, int w, int h, const float K[9], const float *midp_guess, const double *rot_guess, const uint8_t *guess_mask, dh_pose *out), (p, frames, n, w, h, K, midp_guess, rot_guess, guess_mask, out))
 DH_API(host_alloc, (size_t bytes, void **out), (bytes, out))

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -184,6 +185,7 @@ Knobs dh_read_knobs_() {
         if (sscanf(e, "%d,%d", &k.tile_x, &k.tile_y) != 2 || k.tile_x < 1 || k.tile_y < 1) k.tile_x = k.tile_y = 0;
     }
     k.box_band = std::max(1, geti("DH_BOX_BAND", 64));
+    k.box_bands = std::max(0, geti("DH_BOX_BANDS", 0));
     k.max_resident = std::max(1, geti("DH_MAX_RESIDENT_FRAMES", 512));
     k.chunks = std::max(0, std::min(8, geti("DH_CHUNKS", 0)));
     k.box_dense = getenv("DH_BOX_DENSE") != nullptr;
@@ -355,6 +357,30 @@ int dh_choose_tile_(const TileQuery &p, Geom &g) {
 
 // ------------------------------------------------------------------ small numeric tables
 // Mat3<f32>::inv = adjugate / det, element-wise (meancov_estimation.rs:339-352); f32, no FMA
+// k_boxsum's bands (dh_host.h).  Measured on MI355X, 640 x 480, 24 x 24 rectangles, 3 parts (tools/experiments/box_bands_sweep.sh,
+// profiles/r03_experiments.md): the kernel's time is (rows a wave marches; the rh - 1 rows that only fill the ring count half) x
+// (rounds the workgroups need on the chip's slots; a partly filled last round costs half of what it leaves empty).  The rule this
+// replaces -- "as many bands as keep every WAVE resident" -- ignored that waves come in workgroups of four: 512 frames took 2 bands
+// (6 of 8 wave slots used, 1 024 workgroups on 768 slots: 0.28 ms) where 4 bands take 0.19 ms; 320 frames 0.174 -> 0.134 ms.
+int dh_box_bands_(int n, int parts, int rows, int blk, int rh, int wg_slots, int *oh_out) {
+    n = std::max(n, 1); parts = std::max(parts, 1); rows = std::max(rows, 1); blk = std::max(blk, 1); wg_slots = std::max(wg_slots, 1);
+    const int max_bands = std::max(1, (rows + blk - 1) / blk);
+    int best_bands = 1, best_oh = ((rows + blk - 1) / blk) * blk;
+    double best = -1.0;
+    for (int want = 1; want <= max_bands; ++want) {
+        const int oh = (((rows + want - 1) / want + blk - 1) / blk) * blk;        // whole mask blocks per band
+        const int bands = (rows + oh - 1) / oh;
+        if (bands != want && want > 1) continue;                                   // (the same cut as a smaller `want`)
+        const double wgs = (double)n * ((parts * bands + 3) / 4);
+        const double r = wgs / wg_slots;
+        const double rounds = r <= 1.0 ? 1.0 : r + 0.5 * (std::ceil(r) - r);
+        const double cost = (oh + 0.5 * std::max(rh - 1, 0)) * rounds;
+        if (best < 0.0 || cost < best - 1e-9) { best = cost; best_bands = bands; best_oh = oh; }   // ties: fewer bands
+    }
+    if (oh_out) *oh_out = best_oh;
+    return best_bands;
+}
+
 void dh_mat3_inv_f32_(const float m[9], float o[9]) {
     const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
     const float det = a * (e * i - f * h) - d * (b * i - c * h) + g * (b * f - c * e);   // :340-342

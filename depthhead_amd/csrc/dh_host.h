@@ -80,6 +80,7 @@ struct Knobs {
     int lds_budget_kb = 0;            // DH_LDS_BUDGET_KB
     int tile_x = 0, tile_y = 0;       // DH_TILE=px,py
     int box_band = 64;                // DH_BOX_BAND
+    int box_bands = 0;                // DH_BOX_BANDS: bands per frame of the LDS-ring k_boxsum (0 = chosen by dh_box_bands_)
     int max_resident = 512;           // DH_MAX_RESIDENT_FRAMES
     int chunks = 0;                   // DH_CHUNKS: forked sub-batches per call; 0 = automatic (two once a call brings >= 512 frames)
     bool box_dense = false;           // DH_BOX_DENSE: k_boxsum stores every cell (no skipping of zero over zero)
@@ -132,6 +133,10 @@ struct TileQuery {
 // a negative DH_E* (message set), or 1 = "no tile fits the uniform layout: retry on the general path".
 int dh_choose_tile_(const TileQuery &q, Geom &g);
 static const int kBoxSpan = 256, kBoxMaxRect = 96;   // image columns one k_boxsum wave spans; largest rectangle edge it serves
+// Bands a frame is cut into by the LDS-ring k_boxsum for a batch of n frames: band height `*oh` (whole mask blocks of `blk` rows)
+// and the number of bands.  A workgroup is 4 waves = 4 (part, band) units and the chip holds `wg_slots` of them (3 per CU: the
+// ring's LDS); a wave marches its band + rh - 1 rows.  Picks the band count with the smallest (march) x (rounds of workgroups).
+int dh_box_bands_(int n, int parts, int rows, int blk, int rh, int wg_slots, int *oh);
 
 // ------------------------------------------------------------------ small numeric tables (f32, no FMA: -ffp-contract=off)
 void dh_mat3_inv_f32_(const float m[9], float o[9]);                 // Mat3<f32>::inv (meancov_estimation.rs:339-352)

@@ -85,9 +85,9 @@ def predict_stream(hp, frames, intrinsic, group=None) -> np.ndarray:
 
 class ShardedPredictor:
     """The steady-state form of `predict_stream` for device-resident shards (what `bench.py --gpus N` times):
-    this rank's `n_local` frames already sit in HBM; `submit()` enqueues the local batch and starts the all-gather of
-    its pose records (on RCCL's own stream, asynchronous); `wait()`-free: buffers alternate so that the gather of
-    step i overlaps the kernels of step i + 1, and `fence()` drains everything.
+    this rank's `n_local` frames already sit in HBM; `submit()` enqueues the local batch and, on the same stream behind its
+    kernels, the all-gather of its pose records; nothing waits on the host: buffers alternate so that the gather of
+    step i overlaps the kernels of step i + 1 (other streams), and `fence()` drains everything.
 
     `hp` may be ONE predictor or a list of them (pipeline depth = len): consecutive steps then alternate between the
     predictors, each on a stream of its own, so that the latency-bound tail kernels of batch i (vote, mean shift) run
@@ -120,6 +120,11 @@ class ShardedPredictor:
         self.gathered = [torch.zeros(self.world * nb, dtype=torch.uint8, device=gdev) for _ in range(self.slots)] if self.collective else None
         self.pending = [None] * self.slots
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.depth)] if self.depth > 1 else None
+        if self.depth > 1:
+            # several predictors in flight ARE the overlap that the library's forked sub-batches (calls of >= 512 frames) would
+            # add, without the fork's event plumbing: 512 frames per call, four in flight, 669 k frames/s forked, 713 k whole
+            for q in self.hps:
+                q.set_forking(1)
         self.count = 0
         self.graph = False
 
@@ -143,8 +148,7 @@ class ShardedPredictor:
             # `decode_depth_device`) has to be finished before k_boxsum reads them
             st.wait_stream(stream)
         if self.pending[b] is not None:
-            with torch.cuda.stream(st):                 # the stream that is about to overwrite the buffer waits for its last gather
-                self.pending[b].wait()
+            self.pending[b].wait()                      # (gloo rehearsal only: the staged gather that last used this buffer pair)
             self.pending[b] = None
         if self.graph:
             self.hp.graph_launch(st.cuda_stream)
@@ -152,9 +156,17 @@ class ShardedPredictor:
             self.hps[k].predict_batch_device(frames_ptr, self.n_local, self.w, self.h, self.intrinsic, self.pose_bufs[b].data_ptr(),
                                              stream=st.cuda_stream)
         if self.collective:
-            with torch.cuda.stream(st):                 # the collective (or the staging copy) orders itself after this step's kernels
-                src = self.pose_bufs[b] if self.on_device else self.pose_bufs[b].cpu()
-                self.pending[b] = self.dist.all_gather_into_tensor(self.gathered[b], src, group=self.group, async_op=True)
+            with torch.cuda.stream(st):
+                if self.on_device:
+                    # RCCL: the collective is a node of THIS step's stream (a synchronous-mode c10d collective is enqueued under the
+                    # current stream and does not block the host), ordered after the step's kernels and before whatever next
+                    # touches the buffer pair on that stream -- no work object, no events between streams, no wait before the
+                    # next k_boxsum.  With async_op=True every step paid for two cross-stream events and a barrier packet in front
+                    # of its first kernel: one MI355X, one rank through RCCL, 713 k frames/s against 737 k this way and 739 k
+                    # with no collective at all (tools/experiments/dist_overhead.py, profiles/r03_experiments.md).
+                    self.dist.all_gather_into_tensor(self.gathered[b], self.pose_bufs[b], group=self.group)
+                else:
+                    self.pending[b] = self.dist.all_gather_into_tensor(self.gathered[b], self.pose_bufs[b].cpu(), group=self.group, async_op=True)
         return b
 
     def fence(self):

@@ -250,6 +250,10 @@ class HoughPrediction:
     def reserve(self, n: int, w: int, h: int) -> None:
         check(self._lib.dh_predictor_reserve(self._ph, C.c_int(n), C.c_int(w), C.c_int(h)))
 
+    def set_forking(self, chunks: int) -> None:
+        """Forked sub-batches inside one device call (`dh_predictor_set_forking`): 0 automatic, 1 never, 2 .. 8 forced."""
+        check(self._lib.dh_predictor_set_forking(self._ph, C.c_int(chunks)))
+
     def patch_grid(self, w: int, h: int) -> tuple[int, int]:
         nx, ny = C.c_int(), C.c_int()
         prm = self._cparams()

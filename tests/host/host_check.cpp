@@ -367,6 +367,23 @@ static void test_tables_and_knobs() {
             CHECK(n <= 300 && memcmp(&full[((size_t)x * 20 + y) * 20 + z], &r2[(size_t)n], 4) == 0);
         }
     }
+    // k_boxsum's bands: whole mask blocks, every row covered once, and the choices measured on MI355X (profiles/r03_experiments.md)
+    {
+        int oh = 0;
+        CHECK(dh_box_bands_(256, 3, 457, 32, 24, 768, &oh) == 4 && oh == 128);      // the headline batch: 768 workgroups, one round
+        CHECK(dh_box_bands_(512, 3, 457, 32, 24, 768, &oh) == 4 && oh == 128);      // (the wave-count rule took 2: 0.28 instead of 0.19 ms)
+        CHECK(dh_box_bands_(320, 3, 457, 32, 24, 768, &oh) == 5 && oh == 96);
+        CHECK(dh_box_bands_(128, 3, 457, 32, 24, 768, &oh) == 8 && oh == 64);
+        CHECK(dh_box_bands_(1, 1, 217, 8, 24, 768, &oh) == 28 && oh == 8);           // one 320 x 240 frame: the shortest bands
+        for (int n : {1, 2, 7, 64, 100, 256, 300, 512, 4096})
+            for (int rows : {1, 5, 31, 32, 33, 217, 457, 1000})
+                for (int blk : {8, 16, 32})
+                    for (int parts : {1, 3, 5}) {
+                        const int b = dh_box_bands_(n, parts, rows, blk, 24, 768, &oh);
+                        CHECK(b >= 1 && oh >= blk && oh % blk == 0 && b == (rows + oh - 1) / oh && (long)b * oh >= rows && (long)(b - 1) * oh < rows);
+                    }
+        CHECK(dh_box_bands_(0, 0, 0, 0, 0, 0, &oh) == 1 && oh == 1);                 // degenerate arguments are clamped
+    }
     CHECK(dh_blur_taps_(8.0f, k) == DH_OK && k.size() == 33 && k[16] > k[15] && k[0] == k[32]);
     CHECK(dh_blur_taps_(0.0f, k) == DH_EINVAL && dh_blur_taps_(5000.0f, k) == DH_ESIZE);
     const float m[9] = {560, 0, 320, 0, 560, 240, 0, 0, 1};

@@ -484,3 +484,39 @@ def test_forked_sub_batches_keep_their_own_tags(hp_mod, oracle, chunks):
                 assert _poses_equal(got, ref[:m]), (chunks, rep)
     finally:
         os.environ.pop("DH_CHUNKS", None)
+
+
+@pytest.mark.gpu
+def test_set_forking_and_batches_beyond_one_round_of_boxsum_workgroups(hp_mod, oracle):
+    """dh_predictor_set_forking (0 automatic / 1 never / n forced) and k_boxsum's band rule (dh_box_bands_) for batches whose
+    workgroups do not fit the chip at once: 320 and 512 device-resident 640 x 480 frames in ONE kernel sequence (5 and 4 bands per
+    frame instead of the 3 and 2 the wave-count rule took), forked in two and three, and automatic; every pose against the oracle's
+    (the frames are replicas of 16 distinct ones).  Arguments outside 0 .. 8 are refused."""
+    torch = pytest.importorskip("torch")
+    from depthhead_amd._lib import POSE_DTYPE, DepthheadError
+    forest = synth.fit_forest(10, 15, synth.FOREST_SEED_BASE + 2)
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 640, 480
+    K = synth.default_intrinsic(w, h)
+    base = synth.biwi_batch(16, w, h, first=420)
+    base[3] = 0
+    ref16 = oracle.predict_batch(forest, model, base, K)
+    dev = torch.device("cuda:0")
+    intr = hp_mod.IntrinsicMatrix(K)
+    st = torch.cuda.current_stream(dev)
+    with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+        for bad in (-1, 9):
+            with pytest.raises(DepthheadError):
+                hp.set_forking(bad)
+        for n in (320, 512):
+            idx = (np.arange(n) * 7) % 16
+            fr = torch.from_numpy(base[idx].view(np.int16)).to(dev)
+            out = torch.zeros(n * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            for chunks in (1, 2, 0, 3, 1):
+                hp.set_forking(chunks)
+                out.zero_()
+                hp.predict_batch_device(fr.data_ptr(), n, w, h, intr, out.data_ptr(), stream=st.cuda_stream)
+                st.synchronize()
+                got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)
+                assert _poses_equal(got, ref16[idx]), (n, chunks)
+            del fr, out
