@@ -40,8 +40,11 @@ N_CUS, N_SIMDS = 256, 1024
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: a timed region of 100 steps (36 ms at the headline workload) -- the region starts on an idle GPU and ends with the
+    # last batch's tail kernels running alone, which costs 20 steps 3 % and 100 steps 0.6 % (708 k / 721 k / 728 k frames/s at
+    # 20 / 60 / 200 steps on one box, tools/experiments/dist_steps.sh)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=None,
                     help="frames per GPU per step; default 256 (BASELINE configs[1]), and 512 with --gpus 8 (configs[3]: 4 096 frames over 8 GPUs)")
     ap.add_argument("--width", type=int, default=640)
