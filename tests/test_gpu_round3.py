@@ -489,8 +489,8 @@ def test_forked_sub_batches_keep_their_own_tags(hp_mod, oracle, chunks):
 @pytest.mark.gpu
 def test_set_forking_and_batches_beyond_one_round_of_boxsum_workgroups(hp_mod, oracle):
     """dh_predictor_set_forking (0 automatic / 1 never / n forced) and k_boxsum's band rule (dh_box_bands_) for batches whose
-    workgroups do not fit the chip at once: 320 and 512 device-resident 640 x 480 frames in ONE kernel sequence (5 and 4 bands per
-    frame instead of the 3 and 2 the wave-count rule took), forked in two and three, and automatic; every pose against the oracle's
+    workgroups do not fit the chip at once: 257 ... 512 device-resident 640 x 480 frames in ONE kernel sequence (320 and 512: 5 and 4
+    bands per frame instead of the 3 and 2 the wave-count rule took), forked in two and three, and automatic; every pose against the oracle's
     (the frames are replicas of 16 distinct ones).  Arguments outside 0 .. 8 are refused."""
     torch = pytest.importorskip("torch")
     from depthhead_amd._lib import POSE_DTYPE, DepthheadError
@@ -508,7 +508,7 @@ def test_set_forking_and_batches_beyond_one_round_of_boxsum_workgroups(hp_mod, o
         for bad in (-1, 9):
             with pytest.raises(DepthheadError):
                 hp.set_forking(bad)
-        for n in (320, 512):
+        for n in (257, 320, 449, 512):             # 5 / 5 / 4 / 4 bands per frame
             idx = (np.arange(n) * 7) % 16
             fr = torch.from_numpy(base[idx].view(np.int16)).to(dev)
             out = torch.zeros(n * POSE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
