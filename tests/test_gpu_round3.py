@@ -520,3 +520,27 @@ def test_set_forking_and_batches_beyond_one_round_of_boxsum_workgroups(hp_mod, o
                 got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=POSE_DTYPE)
                 assert _poses_equal(got, ref16[idx]), (n, chunks)
             del fr, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bands", ["1", "3", "7", "99"])
+def test_forced_boxsum_bands_do_not_change_results(hp_mod, oracle, bands):
+    """DH_BOX_BANDS (the experiments' switch for the number of bands k_boxsum cuts a frame into, LDS-ring path): whatever the cut --
+    one band, bands that do not divide the rows, more bands than mask blocks (clamped) -- every pose matches the oracle's, also on
+    the second batch through the same workspace (the zero-skip masks of the first cut's blocks are reused)."""
+    forest = synth.fit_forest(6, 10, synth.FOREST_SEED_BASE + 9, n_frames=12, subset=1500)
+    model = synth.ModelParams(stepwidth=4)
+    w, h = 320, 240
+    K = synth.default_intrinsic(w, h)
+    a = synth.biwi_batch(12, w, h, first=130)
+    b = synth.biwi_batch(12, w, h, first=500)
+    b[4] = 0
+    ra, rb = oracle.predict_batch(forest, model, a, K), oracle.predict_batch(forest, model, b, K)
+    os.environ["DH_BOX_BANDS"] = bands
+    try:
+        with hp_mod.HoughPrediction(forest, model, device=0) as hp:
+            intr = hp_mod.IntrinsicMatrix(K)
+            for frames, ref in ((a, ra), (b, rb), (a, ra)):
+                assert _poses_equal(hp.predict_batch(frames, intr), ref), bands
+    finally:
+        os.environ.pop("DH_BOX_BANDS", None)
