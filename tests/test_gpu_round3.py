@@ -42,7 +42,7 @@ def _free_port():
 # ------------------------------------------------------------------ the RCCL gather, executed
 def test_rccl_all_gather_path_on_one_gpu(oracle, hip_lib, tmp_path):
     """`bench.py --gpus 1 --force-dist` launched by torch.distributed.run with ONE rank: the process group is initialised
-    with the `nccl` backend (= RCCL on ROCm) on this box's GPU and every step goes through ShardedPredictor's asynchronous
+    with the `nccl` backend (= RCCL on ROCm) on this box's GPU and every step goes through ShardedPredictor's stream-ordered
     `all_gather_into_tensor` on DEVICE buffers -- the code path the 8-GPU run takes (bench.py's init_process_group,
     dist.py's collective, the MAX all-reduce of the timing, barrier, destroy).  The gathered poses of the last timed step
     equal the oracle's.  A fresh child process, never an exec of this one."""
