@@ -589,7 +589,11 @@ static int enqueue_range(dh_predictor *p, const uint16_t *frames, int f0, int n,
             // duration there: 31 instead of 55 rows at rh = 24; one 320 x 240 frame 86 -> 79 us with 16-row bands, 76 with 8)
             const int blk = 1 << p->blk_shift;
             int oh = 0;
-            int bands = dh_box_bands_(n, g.box_parts, g.box_rows, blk, p->f_rh, 3 * 256, &oh);
+            // workgroups the chip holds at once: per CU what the ring's LDS leaves room for (53 KB at rh = 24: three), at most the six
+            // that 76 VGPRs allow; 256 CUs
+            const size_t lds_wg = (size_t)4 * (p->f_rh - 1) * 64 * 8 + (size_t)4 * (256 + 96 + 8) * 4;
+            const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(6, ((size_t)160 * 1024) / lds_wg));
+            int bands = dh_box_bands_(n, g.box_parts, g.box_rows, blk, p->f_rh, wg_per_cu * 256, &oh);
             if (p->knobs.box_bands > 0) {                     // DH_BOX_BANDS: experiments
                 bands = std::min(p->knobs.box_bands, std::max(1, (g.box_rows + blk - 1) / blk));
                 oh = ((g.box_rows + bands - 1) / bands + blk - 1) & ~(blk - 1);

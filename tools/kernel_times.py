@@ -12,7 +12,9 @@ a = sys.argv[1:]
 kind = a[0] if len(a) > 0 else "fitted"
 trees, depth, stride = (int(a[i]) if len(a) > i else d for i, d in ((1, 10), (2, 15), (3, 4)))
 W, H, NF, reps = (int(a[i]) if len(a) > i else d for i, d in ((4, 640), (5, 480), (6, 256), (7, 10)))
-forest = (synth.fit_forest if kind == "fitted" else synth.synth_forest)(trees, depth, synth.FOREST_SEED_BASE + 2)
+rs = os.environ.get("KT_RECT_SCALE")          # synth only: rectangle edge as a fraction of the patch (0.3 = the trainer's 24 x 24)
+forest = (synth.synth_forest(trees, depth, synth.FOREST_SEED_BASE + 2, rect_scale=float(rs)) if rs and kind != "fitted"
+          else (synth.fit_forest if kind == "fitted" else synth.synth_forest)(trees, depth, synth.FOREST_SEED_BASE + 2))
 dev = torch.device("cuda:0")
 nd = min(64, NF)
 fa = np.concatenate([synth.biwi_batch(nd, W, H)] * ((NF + nd - 1) // nd))[:NF]
